@@ -1,0 +1,203 @@
+"""CPU: the oracle (oracle/) against every golden vector produced by the real reference
+(tests/golden/make_golden.py).  This is what pins the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import graph_adjacency, stgcn
+from tests.util import load_npz, sub, ckpt, assert_close, assert_grad_close, feeds_train_bn
+
+F32 = 2e-5      # fp32 restatement vs fp32 reference: op-order noise only
+
+
+def test_graph_all_strategies():
+    g = load_npz("graph")
+    for strat in ("uniform", "distance", "spatial"):
+        np.testing.assert_array_equal(graph_adjacency(strat), g[strat])
+    np.testing.assert_array_equal(graph_adjacency("spatial", max_hop=2), g["spatial_hop2"])
+    np.testing.assert_array_equal(graph_adjacency("distance", max_hop=2), g["distance_hop2"])
+    A = graph_adjacency("spatial")
+    assert A.shape == (3, 16, 16) and int((A != 0).sum()) == 46
+    np.testing.assert_allclose(A.sum(axis=(0, 1)), 1.0)
+
+
+@pytest.mark.parametrize("tag", ["f64_small", "f32_b0", "f32_b1", "T_f64_small", "T_f32_b0", "T_f32_b1"])
+def test_graph_conv_fwd_bwd(tag):
+    d = sub(load_npz("gcn"), tag + ".")
+    tr = tag.startswith("T_")
+    x = d["x"].clone().requires_grad_(True)
+    A = d["A"].clone().requires_grad_(True)
+    w = d["w"].clone().requires_grad_(True)
+    b = d["b"].clone().requires_grad_(True)
+    y = stgcn.conv_temporal_graphical(x, A, w, b, transposed=tr)
+    tol = 1e-12 if "f64" in tag else F32
+    assert_close(y, d["y"], tol, "y")
+    y.backward(d["gy"])
+    for got, key in ((x.grad, "gx"), (A.grad, "gA"), (w.grad, "gw"), (b.grad, "gb")):
+        assert_close(got, d[key], tol * 5, key)
+
+
+def _block_cases():
+    out = []
+    for f in ("st_gcn_blocks", "st_gctn_blocks"):
+        tags = sorted({k.split(".")[0] for k in load_npz(f).files})
+        out += [(f, t) for t in tags]
+    return out
+
+
+def block_meta(tag):
+    parts = tag.split("_")
+    transposed = parts[0] == "t"
+    cin, cout = int(parts[1]), int(parts[2])
+    stride = 2 if "s2" in parts else 1
+    residual = "nores" not in parts
+    return transposed, cin, cout, stride, residual
+
+
+@pytest.mark.parametrize("fname,tag", _block_cases())
+@pytest.mark.parametrize("mode", ["train", "eval"])
+def test_st_gcn_block(fname, tag, mode):
+    z = load_npz(fname)
+    transposed, cin, cout, stride, residual = block_meta(tag)
+    P = sub(z, tag + ".P0.")
+    P = {"blk." + k: v.clone() for k, v in P.items()}
+    d = sub(z, "%s.%s." % (tag, mode))
+    keys = [k for k in P if not k.endswith(("running_mean", "running_var", "num_batches_tracked"))]
+    for k in keys:
+        P[k].requires_grad_(True)
+    x = d["x"].clone().requires_grad_(True)
+    A = d["A"].clone().requires_grad_(True)
+    y = stgcn.st_gcn_block(x, A, P, "blk", stride, residual, mode == "train", transposed)
+    assert_close(y, d["y"], 5e-5, "y")
+    y.backward(d["gy"])
+    assert_close(x.grad, d["gx"], 2e-4, "gx")
+    assert_close(A.grad, d["gA"], 2e-4, "gA")
+    for k in keys:
+        name = k[4:]
+        g = P[k].grad
+        if "G." + name in d:
+            noise = 1e-7 * float(d["gy"].abs().sum()) if (mode == "train" and feeds_train_bn(name)) else 1e-6
+            assert_grad_close(g, d["G." + name], 2e-4, name, noise)
+        else:
+            assert_close(g[:2], d["Gsl." + name], 3e-4, "Gsl " + name)
+            assert abs(float(g.double().norm()) - float(d["Gnorm." + name])) <= 3e-4 * float(d["Gnorm." + name])
+    for k, v in d.items():
+        if k.startswith("P1."):
+            assert_close(P["blk." + k[3:]], v, 2e-5, k)
+
+
+def test_classifier_real_only_ckpt395_eval():
+    P = ckpt("ckpt_classifier_real_only_epoch395")
+    d = sub(load_npz("classifier_real_only_eval"), "")
+    with torch.no_grad():
+        probs, feat = stgcn.classifier_forward(P, d["h5_x"], "real_only")
+        assert_close(probs, d["h5_probs"], 1e-4, "h5 probs")
+        assert_close(feat, d["h5_feat"], 1e-4, "h5 feat")
+        assert torch.equal(probs.argmax(1), d["h5_probs"].argmax(1))
+        probs, feat = stgcn.classifier_forward(P, d["rnd_x"], "real_only")
+        assert_close(probs, d["rnd_probs"], 1e-4, "rnd probs")
+        assert_close(feat, d["rnd_feat"], 1e-4, "rnd feat")
+        o, f = stgcn.classifier_extract_feature(P, d["rnd_x"][:2], "real_only")
+        assert_close(o, d["ef_out"], 1e-4, "extract_feature out")
+        assert_close(f, d["ef_feat"], 1e-4, "extract_feature feat")
+
+
+def test_real_and_synth_and_hybrid_eval_kt75():
+    base = ckpt("ckpt_classifier_real_only_epoch395")
+    d = sub(load_npz("real_and_synth_eval_T240"), "")
+    P = {k: v for k, v in base.items() if not k.startswith("st_gcn_networks.0.residual")}
+    P.update({k[2:]: v for k, v in d.items() if k.startswith("P.")})
+    with torch.no_grad():
+        o, f = stgcn.classifier_forward(P, d["x"], "real_and_synth")
+    assert_close(o, d["out"], 1e-4, "logits")
+    assert_close(f, d["feat"], 1e-4, "feat")
+
+    d = sub(load_npz("hybrid_eval_T1024"), "")
+    P = {k.replace("data_bn.", "data_bn1."): v for k, v in base.items()
+         if not k.startswith(("st_gcn_networks.0.residual", "fcn."))}
+    P.update({k[2:]: v for k, v in d.items() if k.startswith("P.")})
+    with torch.no_grad():
+        o = stgcn.classifier_forward(P, d["x_gait"], "hybrid", x_aff=d["x_aff"])
+    assert_close(o, d["out"], 1e-4, "hybrid logits")
+
+
+@pytest.mark.parametrize("variant", ["real_only", "real_and_synth", "hybrid"])
+def test_train_step_kt9(variant):
+    z = load_npz("train_steps")
+    p = variant + "_k9."
+    d = sub(z, p)
+    P = {k[3:]: v.clone() for k, v in d.items() if k.startswith("P0.")}
+    loss, out, grads = stgcn.classifier_loss_and_grads(P, d["x"], d["labels"], variant,
+                                                       x_aff=d.get("x_aff"))
+    assert abs(float(loss) - float(d["loss"])) < 1e-5
+    assert_close(out, d["out"], 1e-4, "out")
+    for k, g in grads.items():
+        assert_grad_close(g, d["G." + k], 5e-4, k, 1e-6 if feeds_train_bn(k) else 1e-7)
+    # Adam(lr=0.1, wd=1e-4), one step; BN buffers were updated by the forward above
+    params = {k: P[k] for k in grads}
+    stgcn.adam_step(params, grads, {}, lr=0.1, weight_decay=1e-4, step=1)
+    for k in P:
+        if k.endswith("num_batches_tracked"):
+            assert int(P[k]) == int(d["P1." + k])
+        elif k in grads:
+            # Adam's first step is lr*sign(g) wherever |g| >> eps: compare where the
+            # reference gradient is well away from zero
+            ref1, ref0 = d["P1." + k], d["P0." + k]
+            mask = d["G." + k].abs() > 1e-6
+            assert float(((P[k] - ref1).abs() * mask).max()) < 2e-3, k
+        else:
+            assert_grad_close(P[k], d["P1." + k], 1e-4, k, 1e-7)
+
+
+def test_train_step_kt75_ckpt395():
+    z = load_npz("train_steps")
+    d = sub(z, "real_only_k75_ckpt395.")
+    P = ckpt("ckpt_classifier_real_only_epoch395")
+    loss, out, grads = stgcn.classifier_loss_and_grads(P, d["x"], d["labels"], "real_only")
+    assert abs(float(loss) - float(d["loss"])) < 1e-5
+    assert_close(out, d["out"], 1e-4, "out")
+    for k, g in grads.items():
+        if "G." + k in d:
+            assert_grad_close(g, d["G." + k], 1e-3, k, 1e-6 if feeds_train_bn(k) else 1e-7)
+        else:
+            assert_close(g[:2], d["Gsl." + k], 1e-3, k)
+            n = float(d["Gnorm." + k])
+            assert abs(float(g.double().norm()) - n) <= 1e-3 * n, k
+    for k, v in d.items():
+        if k.startswith("P1.") and "running" in k:
+            assert_close(P[k[3:]], v, 1e-4, k)
+
+
+def test_cvae_ckpt105():
+    P = ckpt("ckpt_cvae_epoch105")
+    d = sub(load_npz("cvae_eval"), "")
+    with torch.no_grad():
+        mean, lsig = stgcn.encoder_forward(P, d["x"], d["lenc"])
+        assert_close(mean, d["mean"], 1e-4, "mean")
+        assert_close(lsig, d["lsig"], 1e-4, "lsig")
+        dec = stgcn.decoder_forward(P, d["z"], d["onehot"], 75, 16)
+        assert_close(dec, d["dec75"], 1e-4, "dec75")
+        dec = stgcn.decoder_forward(P, d["z"][:2], d["onehot"][:2], 240, 16)
+        assert_close(dec, d["dec240"], 1e-4, "dec240")
+
+
+def test_cvae_train_fwd_bwd():
+    P = ckpt("ckpt_cvae_epoch105")
+    d = sub(load_npz("cvae_train"), "")
+    keys = stgcn.trainable_keys(P)
+    for k in keys:
+        P[k].requires_grad_(True)
+    T = d["x"].shape[2]
+    rec, mean, lsig, z = stgcn.cvae_forward(P, d["x"], d["lenc"], d["onehot"], d["eps"], T, 16,
+                                            training=True)
+    assert_close(mean, d["mean"], 1e-4, "mean")
+    assert_close(rec, d["rec"], 1e-4, "rec")
+    loss = ((rec - d["x"]) ** 2).mean() - 0.5 * torch.mean(1 + lsig - mean.pow(2) - lsig.exp())
+    assert abs(float(loss) - float(d["loss"])) < 1e-5
+    loss.backward()
+    for k in keys:
+        g = P[k].grad
+        if "G." + k in d:
+            assert_grad_close(g, d["G." + k], 1e-3, k, 1e-6 if feeds_train_bn(k) else 1e-7)
+        elif "Gsl." + k in d:
+            assert_close(g[:2], d["Gsl." + k], 1e-3, k)

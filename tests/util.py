@@ -1,0 +1,54 @@
+"""Helpers shared by the test modules (fixture loading, comparisons)."""
+import os
+
+import numpy as np
+import torch
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_npz(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+def sub(npz, prefix, dtype=None, device=None):
+    """All arrays under ``prefix`` as torch tensors, prefix stripped."""
+    out = {}
+    for k in npz.files:
+        if k.startswith(prefix):
+            t = torch.from_numpy(np.array(npz[k]))
+            if dtype is not None and t.is_floating_point():
+                t = t.to(dtype)
+            if device is not None:
+                t = t.to(device)
+            out[k[len(prefix):]] = t
+    return out
+
+
+def ckpt(name, dtype=None, device=None):
+    return sub(load_npz(name), "", dtype, device)
+
+
+def relerr(a, b):
+    a = torch.as_tensor(a).detach().double().cpu()
+    b = torch.as_tensor(b).detach().double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def assert_close(a, b, rtol, what=""):
+    e = relerr(a, b)
+    assert e <= rtol, "%s: max-abs error / max|ref| = %.3e > %.1e" % (what, e, rtol)
+
+
+def feeds_train_bn(name):
+    """Conv biases that go straight into a train-mode BatchNorm: their gradient is
+    mathematically zero, what any implementation returns is rounding noise."""
+    return name.endswith(("gcn.conv.bias", "gctn.conv.bias", "tcn.2.bias", "residual.0.bias"))
+
+
+def assert_grad_close(g, ref, rtol, name, noise=0.0):
+    g = torch.as_tensor(g).double().cpu()
+    ref = torch.as_tensor(ref).double().cpu()
+    err = float((g - ref).abs().max())
+    lim = rtol * float(ref.abs().max()) + noise
+    assert err <= lim, "%s: |g-ref|max = %.3e > %.3e" % (name, err, lim)
