@@ -1,0 +1,176 @@
+/*
+ * step_hip.h - C ABI of libstep_hip.so: the MI355X (gfx950) kernels of STEP's ST-GCN
+ * block stack.
+ *
+ * The reference (UttaranB127/STEP) is pure Python/PyTorch and has no FFI layer of its
+ * own: every entry point below replaces the PyTorch library ops that one reference
+ * statement lowers to; the statement is cited as file:line under /root/reference.
+ * The Python host (step_amd/net/...) binds these with ctypes; INTEGRATION.md shows the stub.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller; the library keeps nothing
+ *     after return except work in flight on `stream` (a hipStream_t passed as void*);
+ *   - activations are fp32, contiguous (N, C, T, V) with V == 16 joints (graph.py:41);
+ *   - return value: 0 on success, a negative step_status otherwise; the message is in
+ *     step_last_error() (thread-local).  Shapes are checked on the host BEFORE a launch;
+ *   - re-entrant; no global mutable state; one process per GPU under data parallelism.
+ */
+#ifndef STEP_HIP_H
+#define STEP_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define STEP_ABI_VERSION 1
+#define STEP_V 16                 /* joints of the gait skeleton, graph.py:41 */
+
+enum step_status {
+    STEP_OK = 0,
+    STEP_ERR_ARG = -1,            /* bad shape / null pointer / unsupported size     */
+    STEP_ERR_LAUNCH = -2,         /* hipGetLastError() after the launch              */
+    STEP_ERR_WORKSPACE = -3       /* workspace too small                             */
+};
+
+int step_abi_version(void);
+const char* step_last_error(void);
+
+/* ---------------------------------------------------------------- BatchNorm --------
+ * group layout `bn_mode`:
+ *   0: group = c        nn.BatchNorm2d over (N,T,V)            classifier.py:154,163,180
+ *   1: group = v*C + c  `data_bn`, BatchNorm1d on (N, V*C, T)  classifier.py:68-74
+ * G = C (mode 0) or V*C (mode 1).  `inner` = T*V.
+ */
+
+/* eval mode: scale = gamma*rsqrt(var+eps), shift = beta - mean*scale (F.batch_norm, training=False) */
+int step_bn_eval_prepare(const float* gamma, const float* beta, const float* running_mean,
+                         const float* running_var, float eps, float* scale, float* shift,
+                         int G, void* stream);
+
+/* train mode: batch statistics of x (biased var for normalisation), running-stat update
+ * (momentum, unbiased var) exactly as nn.BatchNorm; emits mean, invstd, scale, shift.
+ * ws: step_bn_ws_bytes(G) bytes of scratch.  running_* may be NULL (no update).          */
+size_t step_bn_ws_bytes(int G);
+int step_bn_train_prepare(const float* x, int N, int C, int T, int V, int bn_mode,
+                          const float* gamma, const float* beta,
+                          float* running_mean, float* running_var, float momentum, float eps,
+                          float* mean, float* invstd, float* scale, float* shift,
+                          void* ws, size_t ws_bytes, void* stream);
+
+/* out = act( x*scale[g] + shift[g] + (res ? res*rscale[g] + rshift[g] : 0) ); rscale/rshift
+ * NULL means identity.  The tail of st_gcn.forward: `self.relu(self.tcn(x) + res)`
+ * classifier.py:189-191, and the Decoder's final data_bn CVAE_stgcn.py:224-229.            */
+int step_affine_act(const float* x, const float* scale, const float* shift,
+                    const float* res, const float* rscale, const float* rshift,
+                    int relu, float* out, int N, int C, int T, int V, int bn_mode, void* stream);
+
+/* BatchNorm (+ReLU) backward.  g = dy * mask, mask_mode:
+ *   0 none; 1 (mask_src > 0) [mask_src = the block output]; 2 (x*scale+shift > 0) [BN+ReLU].
+ * reduce: sums[2g] = SUM g, sums[2g+1] = SUM g*x   (fp64, 2*G doubles, caller-owned)
+ * apply : training: dx = gamma*invstd*(g - S1/M - xhat*S(g*xhat)/M); eval: dx = g*scale;
+ *         accumulate != 0 adds into dx.  dgamma/dbeta (nullable) are written by apply;
+ *         dx may be NULL (only dgamma/dbeta wanted).  ws: step_bn_ws_bytes(G) bytes.          */
+int step_bn_bwd_reduce(const float* dy, const float* x, const float* mask_src,
+                       const float* scale, const float* shift, int mask_mode,
+                       int N, int C, int T, int V, int bn_mode,
+                       double* sums, void* ws, size_t ws_bytes, void* stream);
+int step_bn_bwd_apply(const float* dy, const float* x, const float* mask_src,
+                      const float* scale, const float* shift, int mask_mode,
+                      const float* mean, const float* invstd, const float* gamma,
+                      const double* sums, int training, int accumulate,
+                      float* dx, float* dgamma, float* dbeta,
+                      int N, int C, int T, int V, int bn_mode,
+                      void* ws, size_t ws_bytes, void* stream);
+/* dx (+)= dy * (mask_src > 0): identity residual branch, classifier.py:170-171 */
+int step_masked_add(const float* dy, const float* mask_src, float* dx, int accumulate,
+                    size_t n, void* stream);
+
+/* ------------------------------------------------------------- graph convolution ----
+ * ConvTemporalGraphical.forward tgcn.py:58-67 (1x1 conv to K*Co channels + einsum
+ * 'nkctv,kvw->nctw') and, with w_transposed, ConvTransposeTemporalGraphical tgcn.py:121-130.
+ * Fused: optional data_bn affine on load (in_scale/in_shift indexed v*Ci+ci), optional
+ * residual branch `Conv2d(Ci,Co,1,stride=(s,1))` classifier.py:175-179 sharing the x tile.
+ *   x (N,Ci,T,16)  w (K*Co,Ci) | (Ci,K*Co) if w_transposed   b (K*Co)
+ *   A_eff (K,16,16) = A * edge_importance (classifier.py:78); a_nnz_max bounds the
+ *   non-zeros per (k, column w) of A_eff (16 = dense, always valid).
+ *   y (N,Co,T,16) raw graph-conv output (pre tcn[0]);  res_out (N,Co,To,16) raw, To=(T-1)/s+1.
+ */
+int step_gcn_fwd(const float* x, const float* in_scale, const float* in_shift,
+                 const float* w, const float* b, int w_transposed,
+                 const float* A_eff, int a_nnz_max, float* y,
+                 const float* res_w, const float* res_b, int res_transposed, float* res_out,
+                 int N, int Ci, int Co, int K, int T, int stride, void* stream);
+
+/* backward of the above (K16 of SURVEY 2.2).  Any of dx, dw/db, dA, dres_w/dres_b may be
+ * NULL.  dA is returned on the support of A_eff only (d importance = A * dA needs no more).
+ * ws: step_gcn_bwd_ws_bytes(...) bytes.                                                    */
+size_t step_gcn_bwd_ws_bytes(int N, int Ci, int Co, int K, int T);
+int step_gcn_bwd(const float* dy, const float* dres, const float* x,
+                 const float* in_scale, const float* in_shift,
+                 const float* w, const float* b, int w_transposed,
+                 const float* A_eff, int a_nnz_max,
+                 const float* res_w, int res_transposed,
+                 float* dx, float* dw, float* db, float* dA, float* dres_w, float* dres_b,
+                 int N, int Ci, int Co, int K, int T, int stride,
+                 void* ws, size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------- temporal convolution ----
+ * tcn[2] = Conv2d(C,C,(Kt,1),(s,1),((Kt-1)//2,0)) classifier.py:156-162 and its
+ * ConvTranspose2d twin CVAE_stgcn.py:359-365, as an fp32 MFMA implicit GEMM.
+ *
+ * Weights are first re-laid out for the matrix cores (once per weight update):
+ *   pack_mode 0: forward of Conv2d          w (Co,Ci,Kt)
+ *             1: forward of ConvTranspose2d w (Ci,Co,Kt), stride 1
+ *             2: input-gradient of Conv2d   w (Co,Ci,Kt), stride 1 or 2
+ *             3: input-gradient of ConvTranspose2d w (Ci,Co,Kt), stride 1
+ * Kt must be 75 or 9 (the reference builds only Kt=75; 9 is the original ST-GCN value).
+ */
+size_t step_tcn_packed_elems(int Co, int Ci, int Kt, int stride, int pack_mode);
+int step_tcn_pack_weight(const float* w, float* wp, int Co, int Ci, int Kt, int stride,
+                         int pack_mode, void* stream);
+
+/* out = epi( conv( pre(in) ) ):
+ *   pre : in*in_scale[c]+in_shift[c] then ReLU if in_relu (tcn[0], tcn[1] applied on load;
+ *         zero padding is applied AFTER it, as in the reference); NULL scale = identity.
+ *   epi : + bias; then if out_scale: *out_scale[c]+out_shift[c] (tcn[3], eval);
+ *         then if res: + res*res_scale[c]+res_shift[c] (NULL res_scale = identity);
+ *         then ReLU if out_relu (classifier.py:189-191, eval-mode fusion).
+ * For pack_mode 0/1: in (N,Ci,Tin,16) -> out (N,Co,Tout,16), Tout=(Tin-1)/s+1.
+ * For pack_mode 2/3 (dgrad): in = dout (N,Co,Tout,16) -> out = din (N,Ci,Tin,16).        */
+int step_tcn_conv(const float* in, const float* in_scale, const float* in_shift, int in_relu,
+                  const float* wp, const float* bias,
+                  const float* out_scale, const float* out_shift,
+                  const float* res, const float* res_scale, const float* res_shift,
+                  int out_relu, float* out,
+                  int N, int Ci, int Co, int Tin, int Tout, int Kt, int stride, int pack_mode,
+                  void* stream);
+
+/* weight gradient: dw[co][ci][j] = SUM_{n,t,v} dout[n,co,t,v] * a[n,ci,s*t+j-pad,v], with
+ * a = relu?(in*in_scale+in_shift) recomputed on load; db[co] = SUM dout.  transposed != 0
+ * writes the ConvTranspose2d layout (Ci,Co,Kt) instead.                                   */
+size_t step_tcn_wgrad_ws_bytes(int N, int Ci, int Co, int Tin, int Tout, int Kt);
+int step_tcn_wgrad(const float* dout, const float* in, const float* in_scale,
+                   const float* in_shift, int in_relu, float* dw, float* db,
+                   int N, int Ci, int Co, int Tin, int Tout, int Kt, int stride, int transposed,
+                   void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------- head ----------
+ * F.avg_pool2d(x, x.size()[2:]) + mean over M=1, classifier.py:81-82                      */
+int step_pool_fwd(const float* x, float* feat, int N, int C, int inner, void* stream);
+int step_pool_bwd(const float* dfeat, float* dx, int N, int C, int inner, void* stream);
+/* y[n,o] = SUM_i x[n,i]*w[o,i] + b[o]  (w_transposed: w[i,o]) - the 1x1 `fcn`
+ * classifier.py:63,86, z_mean/z_lsig CVAE_stgcn.py:105-106, Decoder.fcn :171, hybrid head.   */
+int step_dense_fwd(const float* x, const float* w, const float* b, int w_transposed,
+                   float* y, int N, int I, int O, void* stream);
+int step_dense_bwd(const float* dy, const float* x, const float* w, int w_transposed,
+                   float* dx, float* dw, float* db, int N, int I, int O, void* stream);
+/* F.softmax(x, dim=1) classifier.py:87 and its backward */
+int step_softmax_fwd(const float* x, float* y, int N, int O, void* stream);
+int step_softmax_bwd(const float* dy, const float* y, float* dx, int N, int O, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STEP_HIP_H */

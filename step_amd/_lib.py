@@ -1,0 +1,99 @@
+"""ctypes binding of libstep_hip.so (the C ABI declared in include/step_hip.h).
+
+There is NO fallback: if the shared library is missing or a call fails, this raises.
+Tensors are passed as raw device pointers; the launch stream is torch's current stream.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libstep_hip.so")
+
+P = ctypes.c_void_p
+I = ctypes.c_int
+F = ctypes.c_float
+Z = ctypes.c_size_t
+
+# name -> (restype, argtypes); must match include/step_hip.h
+SIGNATURES = {
+    "step_abi_version": (I, []),
+    "step_last_error": (ctypes.c_char_p, []),
+    "step_bn_eval_prepare": (I, [P, P, P, P, F, P, P, I, P]),
+    "step_bn_ws_bytes": (Z, [I]),
+    "step_bn_train_prepare": (I, [P, I, I, I, I, I, P, P, P, P, F, F, P, P, P, P, P, Z, P]),
+    "step_affine_act": (I, [P, P, P, P, P, P, I, P, I, I, I, I, I, P]),
+    "step_bn_bwd_reduce": (I, [P, P, P, P, P, I, I, I, I, I, I, P, P, Z, P]),
+    "step_bn_bwd_apply": (I, [P, P, P, P, P, I, P, P, P, P, I, I, P, P, P, I, I, I, I, I, P, Z, P]),
+    "step_masked_add": (I, [P, P, P, I, Z, P]),
+    "step_gcn_fwd": (I, [P, P, P, P, P, I, P, I, P, P, P, I, P, I, I, I, I, I, I, P]),
+    "step_gcn_bwd_ws_bytes": (Z, [I, I, I, I, I]),
+    "step_gcn_bwd": (I, [P, P, P, P, P, P, P, I, P, I, P, I, P, P, P, P, P, P,
+                         I, I, I, I, I, I, P, Z, P]),
+    "step_tcn_packed_elems": (Z, [I, I, I, I, I]),
+    "step_tcn_pack_weight": (I, [P, P, I, I, I, I, I, P]),
+    "step_tcn_conv": (I, [P, P, P, I, P, P, P, P, P, P, P, I, P, I, I, I, I, I, I, I, I, P]),
+    "step_tcn_wgrad_ws_bytes": (Z, [I, I, I, I, I, I]),
+    "step_tcn_wgrad": (I, [P, P, P, P, I, P, P, I, I, I, I, I, I, I, I, P, Z, P]),
+    "step_pool_fwd": (I, [P, P, I, I, I, P]),
+    "step_pool_bwd": (I, [P, P, I, I, I, P]),
+    "step_dense_fwd": (I, [P, P, P, I, P, I, I, I, P]),
+    "step_dense_bwd": (I, [P, P, P, I, P, P, P, I, I, I, P]),
+    "step_softmax_fwd": (I, [P, P, I, I, P]),
+    "step_softmax_bwd": (I, [P, P, P, I, I, P]),
+}
+
+_lib = None
+
+
+class StepHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the library once; raise loudly if it is not there."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise StepHipError(
+                "libstep_hip.so not found at %s - build it with `python -c 'import __graft_entry__ as g; "
+                "g.build()'` (hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)          # AttributeError if the symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        if lib.step_abi_version() != 1:
+            raise StepHipError("libstep_hip.so ABI version %d != 1" % lib.step_abi_version())
+        _lib = lib
+    return _lib
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise StepHipError("step_amd kernels need tensors on the GPU (got device %s); there is no "
+                           "CPU path" % t.device)
+    if not t.is_contiguous():
+        raise StepHipError("non-contiguous tensor passed to the C ABI")
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name, *args):
+    """Call an int-returning entry point on torch's current stream; raise on error."""
+    lib = load()
+    conv = [(_ptr(a) if (a is None or isinstance(a, torch.Tensor)) else a) for a in args]
+    rc = getattr(lib, name)(*conv, stream())
+    if rc != 0:
+        raise StepHipError("%s failed (%d): %s" % (name, rc, lib.step_last_error().decode()))
+
+
+def query(name, *args):
+    """Call a size_t-returning helper."""
+    return getattr(load(), name)(*args)

@@ -1,0 +1,406 @@
+// BatchNorm statistics / affine / backward kernels (HBM-bound, fp32 data, fp64 partial sums).
+//
+// Replaces nn.BatchNorm2d (tcn[0], tcn[3], residual[1]: classifier.py:154,163,180) and the
+// `data_bn` BatchNorm1d on the (N, V*C, T) view (classifier.py:68-74) in both modes, the
+// add + ReLU tail of st_gcn.forward (classifier.py:189-191) and their autograd backward.
+//
+// Layout: x is (N, C, T, V=16) contiguous.  A block owns one channel c and one chunk of
+// the batch; 4 lanes cover one 64-byte (t, :) row with float4 loads, so a wavefront reads
+// 1 KiB contiguous.  Per-lane partial sums are reduced through LDS in a fixed order and
+// written as fp64 partials [chunk][group][2]; a one-block finalize sums the chunks in order,
+// so results are bit-reproducible run to run.
+#include "common.h"
+
+namespace {
+
+constexpr int BN_THREADS = 256;
+constexpr int BN_MAX_CHUNKS = 256;
+
+__device__ __forceinline__ int group_of(int c, int v, int C, int mode) {
+    return mode ? v * C + c : c;
+}
+
+// g = dy * mask ; returns g for 4 consecutive v
+template <int MASK>
+__device__ __forceinline__ float4 masked(const float4 dy, const float4 x, const float4 m,
+                                         const float4 sc, const float4 sh) {
+    float4 g = dy;
+    if (MASK == 1) {
+        g.x = m.x > 0.f ? dy.x : 0.f; g.y = m.y > 0.f ? dy.y : 0.f;
+        g.z = m.z > 0.f ? dy.z : 0.f; g.w = m.w > 0.f ? dy.w : 0.f;
+    } else if (MASK == 2) {
+        g.x = (x.x * sc.x + sh.x) > 0.f ? dy.x : 0.f; g.y = (x.y * sc.y + sh.y) > 0.f ? dy.y : 0.f;
+        g.z = (x.z * sc.z + sh.z) > 0.f ? dy.z : 0.f; g.w = (x.w * sc.w + sh.w) > 0.f ? dy.w : 0.f;
+    }
+    return g;
+}
+
+__device__ __forceinline__ float4 load4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+__device__ __forceinline__ float4 group4(const float* tab, int c, int v0, int C, int mode) {
+    if (!tab) return make_float4(0.f, 0.f, 0.f, 0.f);
+    if (mode == 0) { const float s = tab[c]; return make_float4(s, s, s, s); }
+    return make_float4(tab[(v0 + 0) * C + c], tab[(v0 + 1) * C + c], tab[(v0 + 2) * C + c],
+                       tab[(v0 + 3) * C + c]);
+}
+
+// Block (c, chunk): accumulates A = SUM a, B = SUM b per joint v over rows (n in chunk, t).
+//   STATS: a = x, b = x*x.     BWD: a = g, b = g*x  with g = dy*mask.
+template <bool BWD, int MASK>
+__global__ __launch_bounds__(BN_THREADS) void bn_reduce_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ msrc,
+    const float* __restrict__ scale, const float* __restrict__ shift, double* __restrict__ part,
+    int N, int C, int T, int V, int mode, int nchunks) {
+    const int c = blockIdx.x;
+    const int chunk = blockIdx.y;
+    const int n0 = (int)((long long)N * chunk / nchunks);
+    const int n1 = (int)((long long)N * (chunk + 1) / nchunks);
+    const int tid = threadIdx.x;
+    const int v0 = (tid & 3) * 4;
+    const int slot = tid >> 2;                       // 64 row slots
+    const float4 sc = group4(scale, c, v0, C, mode);
+    const float4 sh = group4(shift, c, v0, C, mode);
+    float a[4] = {0.f, 0.f, 0.f, 0.f}, b[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int n = n0; n < n1; ++n) {
+        const size_t base = ((size_t)n * C + c) * T * 16;
+        for (int t = slot; t < T; t += 64) {
+            const size_t o = base + (size_t)t * 16 + v0;
+            const float4 xv = load4(x + o);
+            if (!BWD) {
+                a[0] += xv.x; a[1] += xv.y; a[2] += xv.z; a[3] += xv.w;
+                b[0] += xv.x * xv.x; b[1] += xv.y * xv.y; b[2] += xv.z * xv.z; b[3] += xv.w * xv.w;
+            } else {
+                const float4 d = load4(dy + o);
+                float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (MASK == 1) m = load4(msrc + o);
+                const float4 g = masked<MASK>(d, xv, m, sc, sh);
+                a[0] += g.x; a[1] += g.y; a[2] += g.z; a[3] += g.w;
+                b[0] += g.x * xv.x; b[1] += g.y * xv.y; b[2] += g.z * xv.z; b[3] += g.w * xv.w;
+            }
+        }
+    }
+    __shared__ double red[2][16][65];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        red[0][v0 + k][slot] = (double)a[k];
+        red[1][v0 + k][slot] = (double)b[k];
+    }
+    __syncthreads();
+    if (tid < 32) {
+        const int which = tid >> 4, v = tid & 15;
+        double s = 0.0;
+        for (int k = 0; k < 64; ++k) s += red[which][v][k];
+        red[which][v][64] = s;
+    }
+    __syncthreads();
+    const int G = mode ? 16 * C : C;
+    double* dst = part + (size_t)chunk * G * 2;
+    if (mode) {
+        if (tid < 32) {
+            const int which = tid >> 4, v = tid & 15;
+            dst[(v * C + c) * 2 + which] = red[which][v][64];
+        }
+    } else if (tid < 2) {
+        double s = 0.0;
+        for (int v = 0; v < 16; ++v) s += red[tid][v][64];
+        dst[c * 2 + tid] = s;
+    }
+}
+
+// sums the chunk partials in order; writes fp64 totals [G][2]
+__global__ void bn_sum_chunks_kernel(const double* __restrict__ part, double* __restrict__ tot,
+                                     int G, int nchunks) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= 2 * G) return;
+    double s = 0.0;
+    for (int k = 0; k < nchunks; ++k) s += part[(size_t)k * G * 2 + e];
+    tot[e] = s;
+}
+
+__global__ void bn_train_finalize_kernel(const double* __restrict__ tot, const float* __restrict__ gamma,
+                                         const float* __restrict__ beta, float* running_mean,
+                                         float* running_var, float momentum, float eps,
+                                         float* mean, float* invstd, float* scale, float* shift,
+                                         int G, double count) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= G) return;
+    const double m = tot[2 * g] / count;
+    double var = tot[2 * g + 1] / count - m * m;
+    var = var > 0.0 ? var : 0.0;
+    const double inv = 1.0 / sqrt(var + (double)eps);
+    const float ga = gamma ? gamma[g] : 1.f, be = beta ? beta[g] : 0.f;
+    mean[g] = (float)m;
+    invstd[g] = (float)inv;
+    const float sc = (float)(ga * inv);
+    scale[g] = sc;
+    shift[g] = (float)((double)be - m * (double)ga * inv);
+    if (running_mean) {
+        const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+        running_mean[g] = (float)((1.0 - momentum) * running_mean[g] + momentum * m);
+        running_var[g] = (float)((1.0 - momentum) * running_var[g] + momentum * unb);
+    }
+}
+
+__global__ void bn_eval_prepare_kernel(const float* gamma, const float* beta, const float* rm,
+                                       const float* rv, float eps, float* scale, float* shift, int G) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= G) return;
+    const float inv = (float)(1.0 / sqrt((double)rv[g] + (double)eps));
+    const float sc = (gamma ? gamma[g] : 1.f) * inv;
+    scale[g] = sc;
+    shift[g] = (beta ? beta[g] : 0.f) - rm[g] * sc;
+}
+
+// out = act(x*scale+shift + res*rscale+rshift), float4 over v
+__global__ __launch_bounds__(256) void affine_act_kernel(
+    const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
+    const float* __restrict__ res, const float* __restrict__ rscale, const float* __restrict__ rshift,
+    int relu, float* __restrict__ out, size_t n4, int C, int T, int mode) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int v0 = (int)(i & 3) * 4;
+        const int c = (int)((i >> 2) / T % C);
+        float4 xv = load4(x + i * 4);
+        if (scale) {
+            const float4 sc = group4(scale, c, v0, C, mode), sh = group4(shift, c, v0, C, mode);
+            xv.x = xv.x * sc.x + sh.x; xv.y = xv.y * sc.y + sh.y;
+            xv.z = xv.z * sc.z + sh.z; xv.w = xv.w * sc.w + sh.w;
+        }
+        if (res) {
+            float4 r = load4(res + i * 4);
+            if (rscale) {
+                const float4 sc = group4(rscale, c, v0, C, mode), sh = group4(rshift, c, v0, C, mode);
+                r.x = r.x * sc.x + sh.x; r.y = r.y * sc.y + sh.y;
+                r.z = r.z * sc.z + sh.z; r.w = r.w * sc.w + sh.w;
+            }
+            xv.x += r.x; xv.y += r.y; xv.z += r.z; xv.w += r.w;
+        }
+        if (relu) {
+            xv.x = fmaxf(xv.x, 0.f); xv.y = fmaxf(xv.y, 0.f);
+            xv.z = fmaxf(xv.z, 0.f); xv.w = fmaxf(xv.w, 0.f);
+        }
+        *reinterpret_cast<float4*>(out + i * 4) = xv;
+    }
+}
+
+// per-group coefficients for the apply pass: dx = g*ka + x*kb + kc
+//   training: ka = gamma*invstd, kb = -ka*invstd*Sgx/M, kc = -ka*S1/M - kb*mean   (Sgx = S2 - mean*S1)
+//   eval    : ka = scale,        kb = 0,                 kc = 0
+__global__ void bn_bwd_coef_kernel(const double* __restrict__ tot, const float* __restrict__ mean,
+                                   const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                   int training, double count, float* __restrict__ coef,
+                                   float* dgamma, float* dbeta, int G) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= G) return;
+    const double S1 = tot[2 * g], S2 = tot[2 * g + 1];
+    const double m = mean[g], inv = invstd[g], ga = gamma ? gamma[g] : 1.0;
+    const double sgx = S2 - m * S1;                 // SUM g*(x-mean)
+    if (dgamma) dgamma[g] = (float)(sgx * inv);
+    if (dbeta) dbeta[g] = (float)S1;
+    const double ka = ga * inv;
+    double kb = 0.0, kc = 0.0;
+    if (training) {
+        kb = -ka * inv * inv * sgx / count;
+        kc = -ka * S1 / count - kb * m;
+    }
+    coef[3 * g] = (float)ka;
+    coef[3 * g + 1] = (float)kb;
+    coef[3 * g + 2] = (float)kc;
+}
+
+template <int MASK>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
+    const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ msrc,
+    const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ coef,
+    int accumulate, float* __restrict__ dx, size_t n4, int C, int T, int mode) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int v0 = (int)(i & 3) * 4;
+        const int c = (int)((i >> 2) / T % C);
+        const float4 xv = load4(x + i * 4);
+        const float4 d = load4(dy + i * 4);
+        float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (MASK == 1) m = load4(msrc + i * 4);
+        float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (MASK == 2) { sc = group4(scale, c, v0, C, mode); sh = group4(shift, c, v0, C, mode); }
+        const float4 g = masked<MASK>(d, xv, m, sc, sh);
+        float r[4];
+        const float gg[4] = {g.x, g.y, g.z, g.w};
+        const float xx[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int grp = group_of(c, v0 + k, C, mode);
+            r[k] = gg[k] * coef[3 * grp] + xx[k] * coef[3 * grp + 1] + coef[3 * grp + 2];
+        }
+        float4 o = make_float4(r[0], r[1], r[2], r[3]);
+        if (accumulate) {
+            const float4 old = load4(dx + i * 4);
+            o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
+        }
+        *reinterpret_cast<float4*>(dx + i * 4) = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void masked_add_kernel(const float* __restrict__ dy,
+                                                         const float* __restrict__ msrc,
+                                                         float* __restrict__ dx, int accumulate,
+                                                         size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const float4 d = load4(dy + i * 4), m = load4(msrc + i * 4);
+        float4 o = make_float4(m.x > 0.f ? d.x : 0.f, m.y > 0.f ? d.y : 0.f, m.z > 0.f ? d.z : 0.f,
+                               m.w > 0.f ? d.w : 0.f);
+        if (accumulate) {
+            const float4 old = load4(dx + i * 4);
+            o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
+        }
+        *reinterpret_cast<float4*>(dx + i * 4) = o;
+    }
+}
+
+int elem_grid(size_t n4) {
+    size_t b = (n4 + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+
+int chunks_for(int N) { return N < BN_MAX_CHUNKS ? N : BN_MAX_CHUNKS; }
+
+// workspace: [chunk partials: MAX_CHUNKS*G*2 doubles][totals: 2G doubles][coef: 3G floats]
+size_t ws_bytes(int G) { return ((size_t)BN_MAX_CHUNKS * G * 2 + 2 * (size_t)G) * 8 + 3 * (size_t)G * 4; }
+
+}  // namespace
+
+extern "C" size_t step_bn_ws_bytes(int G) { return G > 0 ? ws_bytes(G) : 0; }
+
+extern "C" int step_bn_eval_prepare(const float* gamma, const float* beta, const float* running_mean,
+                                    const float* running_var, float eps, float* scale, float* shift,
+                                    int G, void* stream) {
+    STEP_REQUIRE(running_mean && running_var && scale && shift && G > 0, "step_bn_eval_prepare: bad args");
+    hipLaunchKernelGGL(bn_eval_prepare_kernel, dim3(step::ceil_div(G, 128)), dim3(128), 0,
+                       (hipStream_t)stream, gamma, beta, running_mean, running_var, eps, scale, shift, G);
+    return step::check_launch("step_bn_eval_prepare");
+}
+
+#define BN_SHAPE_CHECK(name)                                                                  \
+    STEP_REQUIRE(N > 0 && C > 0 && T > 0 && V == STEP_V, name ": bad shape N=%d C=%d T=%d V=%d (V must be 16)", \
+                 N, C, T, V);                                                                 \
+    STEP_REQUIRE(bn_mode == 0 || bn_mode == 1, name ": bn_mode must be 0 or 1")
+
+extern "C" int step_bn_train_prepare(const float* x, int N, int C, int T, int V, int bn_mode,
+                                     const float* gamma, const float* beta, float* running_mean,
+                                     float* running_var, float momentum, float eps, float* mean,
+                                     float* invstd, float* scale, float* shift, void* ws,
+                                     size_t wsb, void* stream) {
+    BN_SHAPE_CHECK("step_bn_train_prepare");
+    STEP_REQUIRE(x && mean && invstd && scale && shift && ws, "step_bn_train_prepare: null pointer");
+    STEP_REQUIRE((running_mean == nullptr) == (running_var == nullptr),
+                 "step_bn_train_prepare: running stats come in pairs");
+    const int G = bn_mode ? 16 * C : C;
+    if (wsb < ws_bytes(G)) {
+        step::set_error("step_bn_train_prepare: workspace %zu < %zu bytes", wsb, ws_bytes(G));
+        return STEP_ERR_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int nch = chunks_for(N);
+    double* part = (double*)ws;
+    double* tot = part + (size_t)BN_MAX_CHUNKS * G * 2;
+    hipLaunchKernelGGL((bn_reduce_kernel<false, 0>), dim3(C, nch), dim3(BN_THREADS), 0, st, x, nullptr,
+                       nullptr, nullptr, nullptr, part, N, C, T, V, bn_mode, nch);
+    hipLaunchKernelGGL(bn_sum_chunks_kernel, dim3(step::ceil_div(2 * G, 128)), dim3(128), 0, st, part,
+                       tot, G, nch);
+    const double count = bn_mode ? (double)N * T : (double)N * T * 16;
+    hipLaunchKernelGGL(bn_train_finalize_kernel, dim3(step::ceil_div(G, 128)), dim3(128), 0, st, tot,
+                       gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale,
+                       shift, G, count);
+    return step::check_launch("step_bn_train_prepare");
+}
+
+extern "C" int step_affine_act(const float* x, const float* scale, const float* shift,
+                               const float* res, const float* rscale, const float* rshift, int relu,
+                               float* out, int N, int C, int T, int V, int bn_mode, void* stream) {
+    BN_SHAPE_CHECK("step_affine_act");
+    STEP_REQUIRE(x && out, "step_affine_act: null pointer");
+    STEP_REQUIRE((scale == nullptr) == (shift == nullptr) && (rscale == nullptr) == (rshift == nullptr),
+                 "step_affine_act: scale/shift must come in pairs");
+    const size_t n4 = (size_t)N * C * T * 4;
+    hipLaunchKernelGGL(affine_act_kernel, dim3(elem_grid(n4)), dim3(256), 0, (hipStream_t)stream, x,
+                       scale, shift, res, rscale, rshift, relu, out, n4, C, T, bn_mode);
+    return step::check_launch("step_affine_act");
+}
+
+extern "C" int step_bn_bwd_reduce(const float* dy, const float* x, const float* mask_src,
+                                  const float* scale, const float* shift, int mask_mode, int N, int C,
+                                  int T, int V, int bn_mode, double* sums, void* ws, size_t wsb,
+                                  void* stream) {
+    BN_SHAPE_CHECK("step_bn_bwd_reduce");
+    STEP_REQUIRE(dy && x && sums && ws, "step_bn_bwd_reduce: null pointer");
+    STEP_REQUIRE(mask_mode >= 0 && mask_mode <= 2, "step_bn_bwd_reduce: mask_mode %d", mask_mode);
+    STEP_REQUIRE(mask_mode != 1 || mask_src, "step_bn_bwd_reduce: mask_mode 1 needs mask_src");
+    STEP_REQUIRE(mask_mode != 2 || (scale && shift), "step_bn_bwd_reduce: mask_mode 2 needs scale/shift");
+    const int G = bn_mode ? 16 * C : C;
+    if (wsb < ws_bytes(G)) {
+        step::set_error("step_bn_bwd_reduce: workspace %zu < %zu bytes", wsb, ws_bytes(G));
+        return STEP_ERR_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int nch = chunks_for(N);
+    double* part = (double*)ws;
+    dim3 grid(C, nch), blk(BN_THREADS);
+    if (mask_mode == 0)
+        hipLaunchKernelGGL((bn_reduce_kernel<true, 0>), grid, blk, 0, st, x, dy, mask_src, scale, shift,
+                           part, N, C, T, V, bn_mode, nch);
+    else if (mask_mode == 1)
+        hipLaunchKernelGGL((bn_reduce_kernel<true, 1>), grid, blk, 0, st, x, dy, mask_src, scale, shift,
+                           part, N, C, T, V, bn_mode, nch);
+    else
+        hipLaunchKernelGGL((bn_reduce_kernel<true, 2>), grid, blk, 0, st, x, dy, mask_src, scale, shift,
+                           part, N, C, T, V, bn_mode, nch);
+    hipLaunchKernelGGL(bn_sum_chunks_kernel, dim3(step::ceil_div(2 * G, 128)), dim3(128), 0, st, part,
+                       sums, G, nch);
+    return step::check_launch("step_bn_bwd_reduce");
+}
+
+extern "C" int step_bn_bwd_apply(const float* dy, const float* x, const float* mask_src,
+                                 const float* scale, const float* shift, int mask_mode,
+                                 const float* mean, const float* invstd, const float* gamma,
+                                 const double* sums, int training, int accumulate, float* dx,
+                                 float* dgamma, float* dbeta, int N, int C, int T, int V, int bn_mode,
+                                 void* ws, size_t wsb, void* stream) {
+    BN_SHAPE_CHECK("step_bn_bwd_apply");
+    STEP_REQUIRE(dy && x && mean && invstd && sums && ws, "step_bn_bwd_apply: null pointer");
+    STEP_REQUIRE(mask_mode >= 0 && mask_mode <= 2, "step_bn_bwd_apply: mask_mode %d", mask_mode);
+    STEP_REQUIRE(mask_mode != 1 || mask_src, "step_bn_bwd_apply: mask_mode 1 needs mask_src");
+    STEP_REQUIRE(mask_mode != 2 || (scale && shift), "step_bn_bwd_apply: mask_mode 2 needs scale/shift");
+    const int G = bn_mode ? 16 * C : C;
+    if (wsb < ws_bytes(G)) {
+        step::set_error("step_bn_bwd_apply: workspace %zu < %zu bytes", wsb, ws_bytes(G));
+        return STEP_ERR_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    float* coef = (float*)((double*)ws + (size_t)BN_MAX_CHUNKS * G * 2 + 2 * (size_t)G);
+    const double count = bn_mode ? (double)N * T : (double)N * T * 16;
+    hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3(step::ceil_div(G, 128)), dim3(128), 0, st, sums, mean,
+                       invstd, gamma, training, count, coef, dgamma, dbeta, G);
+    if (dx) {
+        const size_t n4 = (size_t)N * C * T * 4;
+        dim3 grid(elem_grid(n4)), blk(256);
+        if (mask_mode == 0)
+            hipLaunchKernelGGL((bn_bwd_apply_kernel<0>), grid, blk, 0, st, dy, x, mask_src, scale, shift,
+                               coef, accumulate, dx, n4, C, T, bn_mode);
+        else if (mask_mode == 1)
+            hipLaunchKernelGGL((bn_bwd_apply_kernel<1>), grid, blk, 0, st, dy, x, mask_src, scale, shift,
+                               coef, accumulate, dx, n4, C, T, bn_mode);
+        else
+            hipLaunchKernelGGL((bn_bwd_apply_kernel<2>), grid, blk, 0, st, dy, x, mask_src, scale, shift,
+                               coef, accumulate, dx, n4, C, T, bn_mode);
+    }
+    return step::check_launch("step_bn_bwd_apply");
+}
+
+extern "C" int step_masked_add(const float* dy, const float* mask_src, float* dx, int accumulate,
+                               size_t n, void* stream) {
+    STEP_REQUIRE(dy && mask_src && dx && n > 0 && (n % 4) == 0, "step_masked_add: bad args");
+    hipLaunchKernelGGL(masked_add_kernel, dim3(elem_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, dy,
+                       mask_src, dx, accumulate, n / 4);
+    return step::check_launch("step_masked_add");
+}

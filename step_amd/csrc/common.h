@@ -1,0 +1,29 @@
+// Shared helpers for libstep_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include "../../include/step_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace step {
+
+void set_error(const char* fmt, ...);
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline int round_up(int a, int b) { return ceil_div(a, b) * b; }
+
+// hipGetLastError after a launch -> status
+int check_launch(const char* what);
+
+}  // namespace step
+
+#define STEP_REQUIRE(cond, ...)                         \
+    do {                                                \
+        if (!(cond)) {                                  \
+            step::set_error(__VA_ARGS__);               \
+            return STEP_ERR_ARG;                        \
+        }                                               \
+    } while (0)

@@ -1,0 +1,276 @@
+// Fused graph convolution of the ST-GCN block (forward).
+//
+// Replaces ConvTemporalGraphical.forward (classifier_stgcn_real_only/net/utils/tgcn.py:58-67):
+//     h = conv1x1(x)  (N, K*Co, T, V);  y = einsum('nkctv,kvw->nctw', h.view(N,K,Co,T,V), A)
+// its transposed twin (tgcn.py:121-130), the `data_bn` affine that precedes block 0
+// (classifier.py:68-74, folded into the load) and the residual 1x1 strided conv of
+// st_gcn (classifier.py:175-179, shares the x tile).
+//
+// Aggregate-first identity:  y[c,(t,w)] = SUM_{k,ci} W[k*Co+c, ci] * z[(k,ci),(t,w)] + bterm[c,w]
+//   z[(k,ci),(t,w)] = SUM_v x[ci,t,v] * A[k,v,w]        (A keeps the skeleton's sparsity)
+//   bterm[c,w]      = SUM_k b[k*Co+c] * SUM_v A[k,v,w]
+// The K*Co-channel intermediate `h` of the reference never exists.  The contraction over
+// (k,ci) runs on the matrix cores (v_mfma_f32_32x32x2_f32: M = Co, N = 32 positions =
+// 2 frames x 16 joints, k-step = 2 input channels); its B operand z is produced on the fly
+// by each lane from the x tile in LDS with the <= EMAX non-zeros of column w of A_k held in
+// registers, so A lives entirely on chip.
+#include "common.h"
+
+namespace {
+
+struct GcnParams {
+    const float* x;
+    const float* in_scale;
+    const float* in_shift;
+    const float* w;
+    const float* b;
+    const float* A;
+    float* y;
+    const float* res_w;
+    const float* res_b;
+    float* res_out;
+    int w_transposed, res_transposed;
+    int N, Ci, Cip, Co, Copad, K, T, To, stride, tiles_per_seq, ntiles;
+};
+
+constexpr int GCN_TT = 8;             // frames per tile
+constexpr int GCN_P = GCN_TT * 16;    // positions per tile
+
+template <int EMAX, int MT>
+__global__ __launch_bounds__(256) void gcn_fwd_kernel(GcnParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int Kq = p.K * p.Cip;
+    float* Ws = smem;                                   // [Kq][Copad]
+    float* xs = Ws + Kq * p.Copad;                      // [Cip][128]
+    float* ellv = xs + p.Cip * GCN_P;                   // [K][EMAX][16]
+    int* elli = reinterpret_cast<int*>(ellv + p.K * EMAX * 16);
+    float* colsum = reinterpret_cast<float*>(elli + p.K * EMAX * 16);   // [K][16]
+    float* bterm = colsum + p.K * 16;                   // [Copad][16]
+    float* Wr = bterm + p.Copad * 16;                   // [Cip][Copad]   (if residual conv)
+    float* br = Wr + (p.res_w ? p.Cip * p.Copad : 0);   // [Copad]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int l31 = lane & 31;
+    const int half = lane >> 5;
+    const int w16 = lane & 15;
+    const int trow = 2 * wave + (l31 >> 4);
+
+    // ---- one-time per block: weights, adjacency pattern, bias term -------------------
+    for (int e = tid; e < Kq * p.Copad; e += 256) {
+        const int c = e % p.Copad;
+        const int q = e / p.Copad;
+        const int ci = q % p.Cip, k = q / p.Cip;
+        float v = 0.f;
+        if (c < p.Co && ci < p.Ci)
+            v = p.w_transposed ? p.w[(size_t)ci * (p.K * p.Co) + k * p.Co + c]
+                               : p.w[((size_t)k * p.Co + c) * p.Ci + ci];
+        Ws[e] = v;
+    }
+    if (p.res_w) {
+        for (int e = tid; e < p.Cip * p.Copad; e += 256) {
+            const int c = e % p.Copad, ci = e / p.Copad;
+            float v = 0.f;
+            if (c < p.Co && ci < p.Ci)
+                v = p.res_transposed ? p.res_w[(size_t)ci * p.Co + c] : p.res_w[(size_t)c * p.Ci + ci];
+            Wr[e] = v;
+        }
+        for (int c = tid; c < p.Copad; c += 256) br[c] = (c < p.Co && p.res_b) ? p.res_b[c] : 0.f;
+    }
+    if (tid < p.K * 16) {
+        const int k = tid >> 4, w = tid & 15;
+        int cnt = 0;
+        float cs = 0.f;
+        for (int v = 0; v < 16; ++v) {
+            const float a = p.A[(k * 16 + v) * 16 + w];
+            cs += a;
+            if (a != 0.f && cnt < EMAX) {
+                ellv[(k * EMAX + cnt) * 16 + w] = a;
+                elli[(k * EMAX + cnt) * 16 + w] = v;
+                ++cnt;
+            }
+        }
+        for (; cnt < EMAX; ++cnt) {
+            ellv[(k * EMAX + cnt) * 16 + w] = 0.f;
+            elli[(k * EMAX + cnt) * 16 + w] = 0;
+        }
+        colsum[k * 16 + w] = cs;
+    }
+    __syncthreads();
+    for (int e = tid; e < p.Copad * 16; e += 256) {
+        const int c = e >> 4, w = e & 15;
+        float s = 0.f;
+        if (c < p.Co && p.b)
+            for (int k = 0; k < p.K; ++k) s += p.b[k * p.Co + c] * colsum[k * 16 + w];
+        bterm[e] = s;
+    }
+
+    // ---- persistent loop over (n, 8-frame) tiles ---------------------------------------
+    for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+        const int n = tile / p.tiles_per_seq;
+        const int t0 = (tile % p.tiles_per_seq) * GCN_TT;
+        __syncthreads();                                  // previous tile's readers are done
+        for (int f = tid; f < p.Cip * 32; f += 256) {
+            const int ci = f >> 5;
+            const int row = (f & 31) >> 2, vq = f & 3;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ci < p.Ci && t0 + row < p.T) {
+                v = *reinterpret_cast<const float4*>(
+                    p.x + (((size_t)n * p.Ci + ci) * p.T + t0 + row) * 16 + vq * 4);
+                if (p.in_scale) {
+                    const int g = vq * 4 * p.Ci + ci;
+                    v.x = v.x * p.in_scale[g] + p.in_shift[g];
+                    v.y = v.y * p.in_scale[g + p.Ci] + p.in_shift[g + p.Ci];
+                    v.z = v.z * p.in_scale[g + 2 * p.Ci] + p.in_shift[g + 2 * p.Ci];
+                    v.w = v.w * p.in_scale[g + 3 * p.Ci] + p.in_shift[g + 3 * p.Ci];
+                }
+            }
+            *reinterpret_cast<float4*>(xs + ci * GCN_P + row * 16 + vq * 4) = v;
+        }
+        __syncthreads();
+
+        const bool live = (t0 + 2 * wave) < p.T;
+        if (live) {
+            f32x16 acc[MT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+            const float* xrow = xs + half * GCN_P + trow * 16;      // + 2*cs*128 per k-step
+            const float* wrow = Ws + half * p.Copad + l31;
+            for (int k = 0; k < p.K; ++k) {
+                float av[EMAX];
+                int ai[EMAX];
+#pragma unroll
+                for (int e = 0; e < EMAX; ++e) {
+                    av[e] = ellv[(k * EMAX + e) * 16 + w16];
+                    ai[e] = elli[(k * EMAX + e) * 16 + w16];
+                }
+                const float* wk = wrow + (size_t)k * p.Cip * p.Copad;
+                for (int cs = 0; cs < p.Cip / 2; ++cs) {
+                    const float* xr = xrow + cs * 2 * GCN_P;
+                    float z = 0.f;
+#pragma unroll
+                    for (int e = 0; e < EMAX; ++e) z = fmaf(av[e], xr[ai[e]], z);
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) {
+                        const float a = wk[cs * 2 * p.Copad + m * 32];
+                        acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, z, acc[m], 0, 0, 0);
+                    }
+                }
+            }
+            const int t = t0 + trow;
+            if (t < p.T) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int c = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                        if (c < p.Co)
+                            p.y[(((size_t)n * p.Co + c) * p.T + t) * 16 + w16] =
+                                acc[m][r] + bterm[c * 16 + w16];
+                    }
+            }
+        }
+
+        // ---- residual 1x1 conv with temporal stride, same x tile -------------------------
+        if (p.res_w) {
+            const int ncol = (p.stride == 1) ? 4 : 2;               // column tiles in this tile
+            const int lrow = (p.stride == 1) ? trow : 2 * trow;     // local input frame
+            if (wave < ncol && (t0 + p.stride * 2 * wave) < p.T) {
+                f32x16 acc[MT];
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+                const float* xr = xs + half * GCN_P + lrow * 16 + w16;
+                const float* wr = Wr + half * p.Copad + l31;
+                for (int cs = 0; cs < p.Cip / 2; ++cs) {
+                    const float bv = xr[cs * 2 * GCN_P];
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) {
+                        const float a = wr[cs * 2 * p.Copad + m * 32];
+                        acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[m], 0, 0, 0);
+                    }
+                }
+                if (t0 + lrow < p.T) {
+                    const int to = (t0 + lrow) / p.stride;
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int c = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                            if (c < p.Co)
+                                p.res_out[(((size_t)n * p.Co + c) * p.To + to) * 16 + w16] =
+                                    acc[m][r] + br[c];
+                        }
+                }
+            }
+        }
+    }
+}
+
+size_t gcn_lds_bytes(const GcnParams& p, int emax) {
+    size_t f = (size_t)p.K * p.Cip * p.Copad + (size_t)p.Cip * GCN_P + 2 * (size_t)p.K * emax * 16 +
+               (size_t)p.K * 16 + (size_t)p.Copad * 16;
+    if (p.res_w) f += (size_t)p.Cip * p.Copad;
+    f += p.Copad;
+    return f * 4;
+}
+
+template <int EMAX, int MT>
+int launch_gcn(const GcnParams& p, hipStream_t st) {
+    const size_t lds = gcn_lds_bytes(p, EMAX);
+    if (lds > 160 * 1024) {
+        step::set_error("step_gcn_fwd: needs %zu bytes of LDS (> 160 KiB) for Ci=%d Co=%d", lds, p.Ci, p.Co);
+        return STEP_ERR_ARG;
+    }
+    auto kern = gcn_fwd_kernel<EMAX, MT>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            step::set_error("step_gcn_fwd: hipFuncSetAttribute(%zu): %s", lds, hipGetErrorString(e));
+            return STEP_ERR_LAUNCH;
+        }
+    }
+    int per_cu = (int)((160 * 1024) / lds);
+    per_cu = per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu);
+    int blocks = 256 * per_cu;
+    if (blocks > p.ntiles) blocks = p.ntiles;
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, st, p);
+    return step::check_launch("step_gcn_fwd");
+}
+
+}  // namespace
+
+extern "C" int step_gcn_fwd(const float* x, const float* in_scale, const float* in_shift,
+                            const float* w, const float* b, int w_transposed, const float* A_eff,
+                            int a_nnz_max, float* y, const float* res_w, const float* res_b,
+                            int res_transposed, float* res_out, int N, int Ci, int Co, int K, int T,
+                            int stride, void* stream) {
+    STEP_REQUIRE(x && w && A_eff && y, "step_gcn_fwd: null pointer");
+    STEP_REQUIRE(N > 0 && Ci > 0 && Co > 0 && T > 0, "step_gcn_fwd: bad shape N=%d Ci=%d Co=%d T=%d", N,
+                 Ci, Co, T);
+    STEP_REQUIRE(K >= 1 && K <= 3, "step_gcn_fwd: K=%d partitions (1..3 supported)", K);
+    STEP_REQUIRE(Co <= 64, "step_gcn_fwd: Co=%d > 64 not built (the reference uses 3/32/64)", Co);
+    STEP_REQUIRE(stride == 1 || stride == 2, "step_gcn_fwd: stride %d", stride);
+    STEP_REQUIRE(a_nnz_max >= 1 && a_nnz_max <= 16, "step_gcn_fwd: a_nnz_max=%d", a_nnz_max);
+    STEP_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "step_gcn_fwd: in_scale/in_shift pair");
+    STEP_REQUIRE((res_w == nullptr) == (res_out == nullptr), "step_gcn_fwd: res_w/res_out pair");
+    GcnParams p{};
+    p.x = x; p.in_scale = in_scale; p.in_shift = in_shift; p.w = w; p.b = b; p.A = A_eff; p.y = y;
+    p.res_w = res_w; p.res_b = res_b; p.res_out = res_out;
+    p.w_transposed = w_transposed; p.res_transposed = res_transposed;
+    p.N = N; p.Ci = Ci; p.Cip = step::round_up(Ci, 2); p.Co = Co; p.Copad = step::round_up(Co, 32);
+    p.K = K; p.T = T; p.stride = stride; p.To = (T - 1) / stride + 1;
+    p.tiles_per_seq = step::ceil_div(T, GCN_TT);
+    const long long nt = (long long)N * p.tiles_per_seq;
+    STEP_REQUIRE(nt <= 0x7fffffffLL, "step_gcn_fwd: too many tiles");
+    p.ntiles = (int)nt;
+    hipStream_t st = (hipStream_t)stream;
+    const int mt = p.Copad / 32;
+    if (a_nnz_max <= 4) return mt == 1 ? launch_gcn<4, 1>(p, st) : launch_gcn<4, 2>(p, st);
+    return mt == 1 ? launch_gcn<16, 1>(p, st) : launch_gcn<16, 2>(p, st);
+}

@@ -1,0 +1,607 @@
+// Backward of the fused graph convolution (gcn.hip).
+//
+// Replaces what autograd runs for ConvTemporalGraphical.forward (tgcn.py:58-67, :121-130)
+// and the residual 1x1 strided conv (classifier.py:175-179): conv dgrad/wgrad, the two bmm's
+// of the einsum backward and the permute copies around them.
+//
+// With  y = Wg * z + bterm,  z[(k,ci),(t,w)] = SUM_v x[ci,t,v] A[k,v,w]  (see gcn.hip):
+//   dz[(k,ci),(t,w)] = SUM_c W[k*Co+c,ci] dy[c,(t,w)]                        (MFMA, kernel 1)
+//   dx[ci,t,v]       = SUM_k SUM_w A[k,v,w] dz[(k,ci),(t,w)]  (+ Wr^T dres)   (LDS scatter, kernel 1)
+//   dA[k,v,w]        = SUM_{n,ci,t} x[ci,t,v] dz[(k,ci),(t,w)] + SUM_c b[k*Co+c] S[c,w]   on supp(A)
+//   dW[k*Co+c,ci]    = SUM_{n,t,w} dy[c,(t,w)] z[(k,ci),(t,w)]               (MFMA, kernel 2)
+//   db[k*Co+c]       = SUM_w colsum_k[w] S[c,w],   S[c,w] = SUM_{n,t} dy[n,c,t,w]
+// Both kernels are persistent over (n, 8-frame) tiles and keep their reductions in registers;
+// per-block partials are summed in block order by a finalize kernel (bit-reproducible).
+#include "common.h"
+
+namespace {
+
+constexpr int TT = 8;
+constexpr int P = TT * 16;        // 128 positions per tile
+constexpr int PS = P + 1;         // odd LDS row stride (kernel 2)
+
+struct GbParams {
+    const float* dy;
+    const float* dres;
+    const float* x;
+    const float* in_scale;
+    const float* in_shift;
+    const float* w;
+    const float* b;
+    const float* A;
+    const float* res_w;
+    float* dx;
+    float* part1;     // kernel 1 partials: [nblk][3][EMAX][16]
+    float* part2;     // kernel 2 partials: [nblk][3*COPAD*CIP + COPAD*16 + COPAD*CIP + COPAD]
+    int w_transposed, res_transposed;
+    int N, Ci, Co, K, T, To, stride, tiles_per_seq, ntiles;
+};
+
+__device__ __forceinline__ int rowmap(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+// column-w non-zeros of A_k into LDS (ELL form), every k < 3 (zero for k >= K)
+template <int EMAX>
+__device__ __forceinline__ void build_ell(const float* A, int K, float* ellv, int* elli, int tid) {
+    if (tid < 48) {
+        const int k = tid >> 4, w = tid & 15;
+        int cnt = 0;
+        if (k < K)
+            for (int v = 0; v < 16; ++v) {
+                const float a = A[(k * 16 + v) * 16 + w];
+                if (a != 0.f && cnt < EMAX) {
+                    ellv[(k * EMAX + cnt) * 16 + w] = a;
+                    elli[(k * EMAX + cnt) * 16 + w] = v;
+                    ++cnt;
+                }
+            }
+        for (; cnt < EMAX; ++cnt) {
+            ellv[(k * EMAX + cnt) * 16 + w] = 0.f;
+            elli[(k * EMAX + cnt) * 16 + w] = 0;
+        }
+    }
+}
+
+__device__ __forceinline__ float4 load_x4(const GbParams& p, int n, int ci, int t, int vq) {
+    float4 v = *reinterpret_cast<const float4*>(p.x + (((size_t)n * p.Ci + ci) * p.T + t) * 16 + vq * 4);
+    if (p.in_scale) {
+        const int g = vq * 4 * p.Ci + ci;
+        v.x = v.x * p.in_scale[g] + p.in_shift[g];
+        v.y = v.y * p.in_scale[g + p.Ci] + p.in_shift[g + p.Ci];
+        v.z = v.z * p.in_scale[g + 2 * p.Ci] + p.in_shift[g + 2 * p.Ci];
+        v.w = v.w * p.in_scale[g + 3 * p.Ci] + p.in_shift[g + 3 * p.Ci];
+    }
+    return v;
+}
+
+// ------------------------------------------------------------------ kernel 1: dx, dA
+template <int CIP, int COPAD, int EMAX>
+__global__ __launch_bounds__(256) void gcn_bwd_data_kernel(GbParams p) {
+    constexpr int KQ = 3 * CIP;
+    constexpr int MQT = (KQ + 31) / 32;
+    constexpr int KQP = MQT * 32;
+    constexpr int MCI = (CIP + 31) / 32;            // ci tiles of the residual product
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Wq = smem;                                // [COPAD][KQP]   W[(k,c),ci] as [c][k*CIP+ci]
+    float* dys = Wq + COPAD * KQP;                   // [COPAD][P]
+    float* xs = dys + COPAD * P;                     // [CIP][P]
+    float* dxs = xs + CIP * P;                       // [CIP][P]
+    float* ellv = dxs + CIP * P;                     // [3][EMAX][16]
+    int* elli = reinterpret_cast<int*>(ellv + 3 * EMAX * 16);
+    float* red = dys;                                // [4][3*EMAX*16], aliases dys after the loop
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5, w16 = lane & 15;
+    const int trow = 2 * wave + (l31 >> 4);
+
+    for (int e = tid; e < COPAD * KQP; e += 256) {
+        const int q = e % KQP, c = e / KQP;
+        const int k = q / CIP, ci = q % CIP;
+        float v = 0.f;
+        if (q < KQ && k < p.K && c < p.Co && ci < p.Ci)
+            v = p.w_transposed ? p.w[(size_t)ci * (p.K * p.Co) + k * p.Co + c]
+                               : p.w[((size_t)k * p.Co + c) * p.Ci + ci];
+        Wq[e] = v;
+    }
+    build_ell<EMAX>(p.A, p.K, ellv, elli, tid);
+    __syncthreads();
+
+    float av[3][EMAX <= 4 ? EMAX : 1];
+    int ai[3][EMAX <= 4 ? EMAX : 1];
+    if (EMAX <= 4) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int e = 0; e < (EMAX <= 4 ? EMAX : 1); ++e) {
+                av[k][e] = ellv[(k * EMAX + e) * 16 + w16];
+                ai[k][e] = elli[(k * EMAX + e) * 16 + w16];
+            }
+    }
+    float dAacc[3][EMAX];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int e = 0; e < EMAX; ++e) dAacc[k][e] = 0.f;
+
+    for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+        const int n = tile / p.tiles_per_seq;
+        const int t0 = (tile % p.tiles_per_seq) * TT;
+        __syncthreads();
+        for (int f = tid; f < COPAD * 32; f += 256) {
+            const int c = f >> 5, row = (f & 31) >> 2, vq = f & 3;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c < p.Co && t0 + row < p.T)
+                v = *reinterpret_cast<const float4*>(
+                    p.dy + (((size_t)n * p.Co + c) * p.T + t0 + row) * 16 + vq * 4);
+            *reinterpret_cast<float4*>(dys + c * P + row * 16 + vq * 4) = v;
+        }
+        for (int f = tid; f < CIP * 32; f += 256) {
+            const int ci = f >> 5, row = (f & 31) >> 2, vq = f & 3;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ci < p.Ci && t0 + row < p.T) v = load_x4(p, n, ci, t0 + row, vq);
+            *reinterpret_cast<float4*>(xs + ci * P + row * 16 + vq * 4) = v;
+            *reinterpret_cast<float4*>(dxs + ci * P + row * 16 + vq * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        __syncthreads();
+
+        // dz = Wq^T . dy : rows q = (k,ci), columns = this wave's 32 positions
+        f32x16 acc[MQT];
+#pragma unroll
+        for (int m = 0; m < MQT; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+        {
+            const float* ap = Wq + half * KQP + l31;
+            const float* bp = dys + half * P + wave * 32 + l31;
+            for (int s = 0; s < COPAD / 2; ++s) {
+                const float bv = bp[s * 2 * P];
+#pragma unroll
+                for (int m = 0; m < MQT; ++m)
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[s * 2 * KQP + m * 32], bv, acc[m], 0, 0, 0);
+            }
+        }
+        // scatter through A^T into dx, and x (x) dz into dA
+#pragma unroll
+        for (int m = 0; m < MQT; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rr = (r & 3) + 8 * (r >> 2);               // row without the lane half
+                const int kq = (m * 32 + rr) / CIP;                   // static for CIP in {8,32,64}
+                if (kq < 3) {
+                    const int q = m * 32 + rr + 4 * half;
+                    const int ci = q - kq * CIP;
+                    const float dz = acc[m][r];
+                    const int base = ci * P + trow * 16;
+#pragma unroll
+                    for (int e = 0; e < EMAX; ++e) {
+                        float a;
+                        int v;
+                        if (EMAX <= 4) { a = av[kq][e]; v = ai[kq][e]; }
+                        else { a = ellv[(kq * EMAX + e) * 16 + w16]; v = elli[(kq * EMAX + e) * 16 + w16]; }
+                        atomicAdd(&dxs[base + v], a * dz);
+                        dAacc[kq][e] = fmaf(xs[base + v], dz, dAacc[kq][e]);
+                    }
+                }
+            }
+
+        // residual branch: dx[ci, s*t', w] += SUM_c Wr[c,ci] dres[c, t', w]
+        if (p.dres) {
+            __syncthreads();                                          // dys no longer needed
+            const int npos = p.stride == 1 ? 128 : 64;
+            const int tr0 = t0 / p.stride;
+            for (int f = tid; f < COPAD * (npos / 4); f += 256) {
+                const int c = f / (npos / 4);
+                const int r4 = f % (npos / 4);
+                const int to = tr0 + (r4 >> 2);
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (c < p.Co && to < p.To)
+                    v = *reinterpret_cast<const float4*>(
+                        p.dres + (((size_t)n * p.Co + c) * p.To + to) * 16 + (r4 & 3) * 4);
+                *reinterpret_cast<float4*>(dys + c * P + r4 * 4) = v;
+            }
+            __syncthreads();
+            if (wave * 32 < npos) {
+                f32x16 ar[MCI];
+#pragma unroll
+                for (int m = 0; m < MCI; ++m)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) ar[m][r] = 0.f;
+                const float* bp = dys + half * P + wave * 32 + l31;
+                for (int s = 0; s < COPAD / 2; ++s) {
+                    const int c = 2 * s + half;
+                    const float bv = bp[s * 2 * P];
+#pragma unroll
+                    for (int m = 0; m < MCI; ++m) {
+                        const int ci = m * 32 + l31;
+                        float a = 0.f;
+                        if (c < p.Co && ci < p.Ci)
+                            a = p.res_transposed ? p.res_w[(size_t)ci * p.Co + c] : p.res_w[(size_t)c * p.Ci + ci];
+                        ar[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, ar[m], 0, 0, 0);
+                    }
+                }
+                const int lrow = p.stride * trow;                     // local input frame
+#pragma unroll
+                for (int m = 0; m < MCI; ++m)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int ci = m * 32 + rowmap(r, half);
+                        if (ci < CIP) atomicAdd(&dxs[ci * P + lrow * 16 + w16], ar[m][r]);
+                    }
+            }
+        }
+        __syncthreads();
+        if (p.dx) {
+            for (int f = tid; f < CIP * 32; f += 256) {
+                const int ci = f >> 5, row = (f & 31) >> 2, vq = f & 3;
+                if (ci < p.Ci && t0 + row < p.T)
+                    *reinterpret_cast<float4*>(p.dx + (((size_t)n * p.Ci + ci) * p.T + t0 + row) * 16 + vq * 4) =
+                        *reinterpret_cast<const float4*>(dxs + ci * P + row * 16 + vq * 4);
+            }
+        }
+    }
+
+    // block partial of dA (ELL form): lanes with equal w -> wave -> block
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int e = 0; e < EMAX; ++e) {
+            float v = dAacc[k][e];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if (lane < 16) red[wave * (3 * EMAX * 16) + (k * EMAX + e) * 16 + lane] = v;
+        }
+    __syncthreads();
+    for (int e = tid; e < 3 * EMAX * 16; e += 256)
+        p.part1[(size_t)blockIdx.x * (3 * EMAX * 16) + e] =
+            (red[e] + red[3 * EMAX * 16 + e]) + (red[2 * 3 * EMAX * 16 + e] + red[3 * 3 * EMAX * 16 + e]);
+}
+
+// -------------------------------------------------------------- kernel 2: dW, S, dWr, dbr
+template <int CIP, int COPAD, int EMAX>
+__global__ __launch_bounds__(256) void gcn_bwd_weight_kernel(GbParams p) {
+    constexpr int MC = COPAD / 32;                   // c tiles
+    constexpr int NCI = (CIP + 31) / 32;             // ci tiles
+    constexpr int CIR = NCI * 32;                    // padded ci rows of the z tile
+    constexpr int NTILE = MC * NCI;                  // output tiles per k (<= 4)
+    constexpr int PART = 3 * COPAD * CIR + COPAD * 16 + COPAD * CIR + COPAD;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* dys = smem;                               // [COPAD][PS]
+    float* xs = dys + COPAD * PS;                    // [CIR][PS]
+    float* zk = xs + CIR * PS;                       // [CIR][PS]
+    float* ellv = zk + CIR * PS;
+    int* elli = reinterpret_cast<int*>(ellv + 3 * EMAX * 16);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int mt = wave / NCI, nt = wave % NCI;      // this wave's (c tile, ci tile) when wave < NTILE
+
+    build_ell<EMAX>(p.A, p.K, ellv, elli, tid);
+    for (int e = tid; e < CIR * PS; e += 256) { xs[e] = 0.f; zk[e] = 0.f; }
+    __syncthreads();
+
+    const int pz = tid & 127;                        // position handled in the z pass
+    const int wz = pz & 15;
+    f32x16 accw[3];
+    f32x16 accr;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { accw[0][r] = 0.f; accw[1][r] = 0.f; accw[2][r] = 0.f; accr[r] = 0.f; }
+    float Sacc[COPAD * 16 / 256];
+#pragma unroll
+    for (int j = 0; j < COPAD * 16 / 256; ++j) Sacc[j] = 0.f;
+    float brsum = 0.f;                               // thread c < COPAD: SUM dres[c]
+
+    for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+        const int n = tile / p.tiles_per_seq;
+        const int t0 = (tile % p.tiles_per_seq) * TT;
+        __syncthreads();
+        for (int f = tid; f < COPAD * 32; f += 256) {
+            const int c = f >> 5, r4 = f & 31;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c < p.Co && t0 + (r4 >> 2) < p.T)
+                v = *reinterpret_cast<const float4*>(
+                    p.dy + (((size_t)n * p.Co + c) * p.T + t0 + (r4 >> 2)) * 16 + (r4 & 3) * 4);
+            float* d = dys + c * PS + r4 * 4;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+        for (int f = tid; f < CIP * 32; f += 256) {
+            const int ci = f >> 5, r4 = f & 31;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ci < p.Ci && t0 + (r4 >> 2) < p.T) v = load_x4(p, n, ci, t0 + (r4 >> 2), r4 & 3);
+            float* d = xs + ci * PS + r4 * 4;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+        __syncthreads();
+        // S[c,w] += SUM_t dy[c,t,w]
+#pragma unroll
+        for (int j = 0; j < COPAD * 16 / 256; ++j) {
+            const int e = tid + j * 256;
+            const int c = e >> 4, w = e & 15;
+            float s = 0.f;
+#pragma unroll
+            for (int t = 0; t < TT; ++t) s += dys[c * PS + t * 16 + w];
+            Sacc[j] += s;
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            if (k < p.K) {
+                // z_k[ci][p] = SUM_e A_k[idx_e, w] x[ci][t, idx_e]
+                float a[EMAX];
+                int ix[EMAX];
+#pragma unroll
+                for (int e = 0; e < EMAX; ++e) {
+                    a[e] = ellv[(k * EMAX + e) * 16 + wz];
+                    ix[e] = elli[(k * EMAX + e) * 16 + wz];
+                }
+                for (int ci = tid >> 7; ci < CIP; ci += 2) {
+                    const float* xr = xs + ci * PS + (pz & ~15);
+                    float z = 0.f;
+#pragma unroll
+                    for (int e = 0; e < EMAX; ++e) z = fmaf(a[e], xr[ix[e]], z);
+                    zk[ci * PS + pz] = z;
+                }
+                __syncthreads();
+                if (wave < NTILE) {
+                    const float* ap = dys + (mt * 32 + l31) * PS + half;
+                    const float* bp = zk + (nt * 32 + l31) * PS + half;
+#pragma unroll 8
+                    for (int s = 0; s < P / 2; ++s)
+                        accw[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * s], bp[2 * s], accw[k], 0, 0, 0);
+                }
+                __syncthreads();
+            }
+        }
+        if (p.dres) {
+            // dWr[c,ci] += SUM_{t',w} dres[c,t',w] x[ci, s*t', w];  dres tile goes into dys
+            const int npos = p.stride == 1 ? 128 : 64;
+            const int tr0 = t0 / p.stride;
+            for (int f = tid; f < COPAD * (npos / 4); f += 256) {
+                const int c = f / (npos / 4), r4 = f % (npos / 4);
+                const int to = tr0 + (r4 >> 2);
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (c < p.Co && to < p.To)
+                    v = *reinterpret_cast<const float4*>(
+                        p.dres + (((size_t)n * p.Co + c) * p.To + to) * 16 + (r4 & 3) * 4);
+                float* d = dys + c * PS + r4 * 4;
+                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            }
+            __syncthreads();
+            if (tid < COPAD) {
+                float s = 0.f;
+                for (int i = 0; i < npos; ++i) s += dys[tid * PS + i];
+                brsum += s;
+            }
+            if (wave < NTILE) {
+                const float* ap = dys + (mt * 32 + l31) * PS + half;
+                const float* bp = xs + (nt * 32 + l31) * PS + half;
+                for (int tl = 0; tl < npos / 16; ++tl) {
+#pragma unroll
+                    for (int v2 = 0; v2 < 8; ++v2)
+                        accr = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                            ap[tl * 16 + 2 * v2], bp[p.stride * tl * 16 + 2 * v2], accr, 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    float* part = p.part2 + (size_t)blockIdx.x * PART;
+    if (wave < NTILE) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int c = mt * 32 + rowmap(r, half);
+                part[(k * COPAD + c) * CIR + nt * 32 + l31] = accw[k][r];
+            }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int c = mt * 32 + rowmap(r, half);
+            part[3 * COPAD * CIR + COPAD * 16 + c * CIR + nt * 32 + l31] = accr[r];
+        }
+    } else {
+        // tiles nobody owns (NTILE < 4 never leaves gaps: every (mt, nt) < NTILE is owned)
+    }
+#pragma unroll
+    for (int j = 0; j < COPAD * 16 / 256; ++j) part[3 * COPAD * CIR + tid + j * 256] = Sacc[j];
+    if (tid < COPAD) part[3 * COPAD * CIR + COPAD * 16 + COPAD * CIR + tid] = brsum;
+}
+
+// ---------------------------------------------------------------------- finalize
+struct FinParams {
+    const float* part1; const float* part2; const float* A; const float* b;
+    float* dw; float* db; float* dA; float* dres_w; float* dres_b;
+    int nblk1, nblk2, emax, copad, cir, Ci, Co, K, w_transposed, res_transposed, have_res;
+};
+
+__global__ void gcn_bwd_finalize_kernel(FinParams f) {
+    const int PART = 3 * f.copad * f.cir + f.copad * 16 + f.copad * f.cir + f.copad;
+    const int offS = 3 * f.copad * f.cir, offR = offS + f.copad * 16, offB = offR + f.copad * f.cir;
+    const int gtid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nW = f.K * f.Co * f.Ci;
+    if (gtid < nW) {                                       // dW
+        if (!f.dw) return;
+        const int ci = gtid % f.Ci, c = (gtid / f.Ci) % f.Co, k = gtid / (f.Ci * f.Co);
+        float s = 0.f;
+        for (int b = 0; b < f.nblk2; ++b) s += f.part2[(size_t)b * PART + (k * f.copad + c) * f.cir + ci];
+        if (f.w_transposed) f.dw[(size_t)ci * (f.K * f.Co) + k * f.Co + c] = s;
+        else f.dw[((size_t)k * f.Co + c) * f.Ci + ci] = s;
+        return;
+    }
+    int e = gtid - nW;
+    if (e < f.Co * f.Ci) {                                 // dWr
+        if (!f.have_res || !f.dres_w) return;
+        const int ci = e % f.Ci, c = e / f.Ci;
+        float s = 0.f;
+        for (int b = 0; b < f.nblk2; ++b) s += f.part2[(size_t)b * PART + offR + c * f.cir + ci];
+        if (f.res_transposed) f.dres_w[(size_t)ci * f.Co + c] = s;
+        else f.dres_w[(size_t)c * f.Ci + ci] = s;
+        return;
+    }
+    e -= f.Co * f.Ci;
+    if (e < f.Co) {                                        // dbr
+        if (!f.have_res || !f.dres_b) return;
+        float s = 0.f;
+        for (int b = 0; b < f.nblk2; ++b) s += f.part2[(size_t)b * PART + offB + e];
+        f.dres_b[e] = s;
+        return;
+    }
+    e -= f.Co;
+    if (e < f.K * f.Co) {                                  // db[k*Co+c] = SUM_w colsum_k[w] S[c,w]
+        if (!f.db) return;
+        const int c = e % f.Co, k = e / f.Co;
+        float tot = 0.f;
+        for (int w = 0; w < 16; ++w) {
+            float S = 0.f;
+            for (int b = 0; b < f.nblk2; ++b) S += f.part2[(size_t)b * PART + offS + c * 16 + w];
+            float cs = 0.f;
+            for (int v = 0; v < 16; ++v) cs += f.A[(k * 16 + v) * 16 + w];
+            tot += cs * S;
+        }
+        f.db[e] = tot;
+        return;
+    }
+    e -= f.K * f.Co;
+    if (e < f.K * 16) {                                    // dA column (k, w), support only
+        if (!f.dA) return;
+        const int w = e & 15, k = e >> 4;
+        float bias_part = 0.f;
+        if (f.b)
+            for (int c = 0; c < f.Co; ++c) {
+                float S = 0.f;
+                for (int b = 0; b < f.nblk2; ++b) S += f.part2[(size_t)b * PART + offS + c * 16 + w];
+                bias_part += f.b[k * f.Co + c] * S;
+            }
+        int cnt = 0;
+        for (int v = 0; v < 16; ++v) {
+            const float a = f.A[(k * 16 + v) * 16 + w];
+            float out = 0.f;
+            if (a != 0.f && cnt < f.emax) {
+                float s = 0.f;
+                for (int b = 0; b < f.nblk1; ++b)
+                    s += f.part1[(size_t)b * (3 * f.emax * 16) + (k * f.emax + cnt) * 16 + w];
+                out = s + bias_part;
+                ++cnt;
+            }
+            f.dA[(k * 16 + v) * 16 + w] = out;
+        }
+    }
+}
+
+struct GbGeom {
+    int cip, copad, emax, cir, nblk1, nblk2;
+    size_t lds1, lds2, part1, part2;
+};
+
+bool gb_geom(int N, int Ci, int Co, int T, int nnz, GbGeom* g) {
+    if (Ci < 1 || Ci > 64 || Co < 1 || Co > 64 || N < 1 || T < 1) return false;
+    g->cip = Ci <= 8 ? 8 : (Ci <= 32 ? 32 : 64);
+    g->copad = Co <= 32 ? 32 : 64;
+    g->emax = nnz <= 4 ? 4 : 16;
+    g->cir = g->cip <= 32 ? 32 : 64;
+    const int kqp = ((3 * g->cip + 31) / 32) * 32;
+    g->lds1 = ((size_t)g->copad * kqp + (size_t)g->copad * P + 2 * (size_t)g->cip * P +
+               2 * 3 * (size_t)g->emax * 16) * 4;
+    g->lds2 = ((size_t)g->copad * PS + 2 * (size_t)g->cir * PS + 2 * 3 * (size_t)g->emax * 16) * 4;
+    const long long ntiles = (long long)N * ((T + TT - 1) / TT);
+    auto blocks = [&](size_t lds) {
+        int per = (int)((160 * 1024) / lds);
+        per = per < 1 ? 1 : (per > 4 ? 4 : per);
+        long long b = 256LL * per;
+        return (int)(b < ntiles ? b : ntiles);
+    };
+    g->nblk1 = blocks(g->lds1);
+    g->nblk2 = blocks(g->lds2);
+    g->part1 = (size_t)3 * g->emax * 16;
+    g->part2 = (size_t)3 * g->copad * g->cir + (size_t)g->copad * 16 + (size_t)g->copad * g->cir + g->copad;
+    return g->lds1 <= 160 * 1024 && g->lds2 <= 160 * 1024;
+}
+
+template <int CIP, int COPAD, int EMAX>
+int launch_gb(const GbParams& p, const GbGeom& g, hipStream_t st) {
+    auto k1 = gcn_bwd_data_kernel<CIP, COPAD, EMAX>;
+    auto k2 = gcn_bwd_weight_kernel<CIP, COPAD, EMAX>;
+    hipError_t e = hipSuccess;
+    if (g.lds1 > 64 * 1024)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k1),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds1);
+    if (e == hipSuccess && g.lds2 > 64 * 1024)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k2),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds2);
+    if (e != hipSuccess) {
+        step::set_error("step_gcn_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        return STEP_ERR_LAUNCH;
+    }
+    hipLaunchKernelGGL(k1, dim3(g.nblk1), dim3(256), g.lds1, st, p);
+    hipLaunchKernelGGL(k2, dim3(g.nblk2), dim3(256), g.lds2, st, p);
+    return step::check_launch("step_gcn_bwd");
+}
+
+template <int EMAX>
+int dispatch_gb(const GbParams& p, const GbGeom& g, hipStream_t st) {
+    const int key = g.cip * 100 + g.copad;
+    switch (key) {
+        case 832: return launch_gb<8, 32, EMAX>(p, g, st);
+        case 864: return launch_gb<8, 64, EMAX>(p, g, st);
+        case 3232: return launch_gb<32, 32, EMAX>(p, g, st);
+        case 3264: return launch_gb<32, 64, EMAX>(p, g, st);
+        case 6432: return launch_gb<64, 32, EMAX>(p, g, st);
+        case 6464: return launch_gb<64, 64, EMAX>(p, g, st);
+    }
+    step::set_error("step_gcn_bwd: no kernel for Ci=%d Co=%d", p.Ci, p.Co);
+    return STEP_ERR_ARG;
+}
+
+}  // namespace
+
+extern "C" size_t step_gcn_bwd_ws_bytes(int N, int Ci, int Co, int K, int T) {
+    (void)K;
+    size_t best = 0;
+    for (int nnz = 4; nnz <= 16; nnz += 12) {             // both kernel variants
+        GbGeom g;
+        if (!gb_geom(N, Ci, Co, T, nnz, &g)) continue;
+        const size_t need = ((size_t)g.nblk1 * g.part1 + (size_t)g.nblk2 * g.part2) * 4;
+        best = need > best ? need : best;
+    }
+    return best;
+}
+
+extern "C" int step_gcn_bwd(const float* dy, const float* dres, const float* x, const float* in_scale,
+                            const float* in_shift, const float* w, const float* b, int w_transposed,
+                            const float* A_eff, int a_nnz_max, const float* res_w, int res_transposed,
+                            float* dx, float* dw, float* db, float* dA, float* dres_w, float* dres_b,
+                            int N, int Ci, int Co, int K, int T, int stride, void* ws, size_t ws_bytes,
+                            void* stream) {
+    STEP_REQUIRE(dy && x && w && A_eff && ws, "step_gcn_bwd: null pointer");
+    STEP_REQUIRE(K >= 1 && K <= 3 && (stride == 1 || stride == 2), "step_gcn_bwd: K=%d stride=%d", K, stride);
+    STEP_REQUIRE(a_nnz_max >= 1 && a_nnz_max <= 16, "step_gcn_bwd: a_nnz_max=%d", a_nnz_max);
+    STEP_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "step_gcn_bwd: in_scale/in_shift pair");
+    STEP_REQUIRE((dres == nullptr) == (res_w == nullptr), "step_gcn_bwd: dres and res_w come together");
+    GbGeom g;
+    STEP_REQUIRE(gb_geom(N, Ci, Co, T, a_nnz_max, &g), "step_gcn_bwd: unsupported N=%d Ci=%d Co=%d T=%d", N,
+                 Ci, Co, T);
+    const size_t need = ((size_t)g.nblk1 * g.part1 + (size_t)g.nblk2 * g.part2) * 4;
+    if (ws_bytes < need) {
+        step::set_error("step_gcn_bwd: workspace %zu < %zu bytes", ws_bytes, need);
+        return STEP_ERR_WORKSPACE;
+    }
+    GbParams p{};
+    p.dy = dy; p.dres = dres; p.x = x; p.in_scale = in_scale; p.in_shift = in_shift; p.w = w; p.b = b;
+    p.A = A_eff; p.res_w = res_w; p.dx = dx;
+    p.part1 = (float*)ws;
+    p.part2 = p.part1 + (size_t)g.nblk1 * g.part1;
+    p.w_transposed = w_transposed; p.res_transposed = res_transposed;
+    p.N = N; p.Ci = Ci; p.Co = Co; p.K = K; p.T = T; p.stride = stride; p.To = (T - 1) / stride + 1;
+    p.tiles_per_seq = (T + TT - 1) / TT;
+    p.ntiles = N * p.tiles_per_seq;
+    hipStream_t st = (hipStream_t)stream;
+    int rc = g.emax == 4 ? dispatch_gb<4>(p, g, st) : dispatch_gb<16>(p, g, st);
+    if (rc) return rc;
+    FinParams f{};
+    f.part1 = p.part1; f.part2 = p.part2; f.A = A_eff; f.b = b;
+    f.dw = dw; f.db = db; f.dA = dA; f.dres_w = dres_w; f.dres_b = dres_b;
+    f.nblk1 = g.nblk1; f.nblk2 = g.nblk2; f.emax = g.emax; f.copad = g.copad; f.cir = g.cir;
+    f.Ci = Ci; f.Co = Co; f.K = K; f.w_transposed = w_transposed; f.res_transposed = res_transposed;
+    f.have_res = dres != nullptr;
+    const int total = K * Co * Ci + Co * Ci + Co + K * Co + K * 16;
+    hipLaunchKernelGGL(gcn_bwd_finalize_kernel, dim3(step::ceil_div(total, 128)), dim3(128), 0, st, f);
+    return step::check_launch("step_gcn_bwd(finalize)");
+}

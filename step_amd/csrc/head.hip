@@ -1,0 +1,165 @@
+// Global average pooling, the small dense heads and softmax.
+//
+// Replaces F.avg_pool2d(x, x.size()[2:]) + mean over M (classifier.py:81-82), the 1x1 `fcn`
+// Conv2d on the pooled (N,64,1,1) feature (classifier.py:63,86), F.softmax (classifier.py:87),
+// z_mean / z_lsig (CVAE_stgcn.py:105-106,131-134), Decoder.fcn (CVAE_stgcn.py:171,208) and the
+// hybrid head's two 1x1 convs (classifier_hybrid/net/classifier.py:47-50,84-85).
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// one wavefront per (n, c): mean over `inner` contiguous floats
+__global__ __launch_bounds__(256) void pool_fwd_kernel(const float* __restrict__ x,
+                                                       float* __restrict__ feat, int NC, int inner) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= NC) return;
+    const int lane = threadIdx.x & 63;
+    const float* src = x + (size_t)row * inner;
+    float s = 0.f;
+    const int n4 = inner >> 2;
+    for (int i = lane; i < n4; i += 64) {
+        const float4 v = *reinterpret_cast<const float4*>(src + i * 4);
+        s += (v.x + v.y) + (v.z + v.w);
+    }
+    for (int i = n4 * 4 + lane; i < inner; i += 64) s += src[i];
+    s = wave_sum(s);
+    if (lane == 0) feat[row] = s / (float)inner;
+}
+
+__global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__ dfeat,
+                                                       float* __restrict__ dx, size_t total,
+                                                       int inner) {
+    const float inv = 1.f / (float)inner;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x)
+        dx[i] = dfeat[i / inner] * inv;
+}
+
+// y[n,o] = b[o] + SUM_i x[n,i] * W(o,i); one thread per output
+__global__ void dense_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                 const float* __restrict__ b, int wt, float* __restrict__ y, int N,
+                                 int I, int O) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= N * O) return;
+    const int n = e / O, o = e % O;
+    float s = b ? b[o] : 0.f;
+    const float* xr = x + (size_t)n * I;
+    if (wt) for (int i = 0; i < I; ++i) s = fmaf(xr[i], w[(size_t)i * O + o], s);
+    else    for (int i = 0; i < I; ++i) s = fmaf(xr[i], w[(size_t)o * I + i], s);
+    y[e] = s;
+}
+
+// dx[n,i] = SUM_o dy[n,o] * W(o,i)
+__global__ void dense_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ w, int wt,
+                                    float* __restrict__ dx, int N, int I, int O) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= N * I) return;
+    const int n = e / I, i = e % I;
+    float s = 0.f;
+    for (int o = 0; o < O; ++o)
+        s = fmaf(dy[(size_t)n * O + o], wt ? w[(size_t)i * O + o] : w[(size_t)o * I + i], s);
+    dx[e] = s;
+}
+
+// dW(o,i) = SUM_n dy[n,o]*x[n,i] (fixed order over n: reproducible); db[o] = SUM_n dy[n,o]
+__global__ void dense_bwd_dw_kernel(const float* __restrict__ dy, const float* __restrict__ x, int wt,
+                                    float* __restrict__ dw, float* __restrict__ db, int N, int I,
+                                    int O) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < O * I) {
+        const int o = e / I, i = e % I;
+        double s = 0.0;
+        for (int n = 0; n < N; ++n) s += (double)dy[(size_t)n * O + o] * (double)x[(size_t)n * I + i];
+        if (dw) dw[wt ? (size_t)i * O + o : (size_t)o * I + i] = (float)s;
+    } else if (e < O * I + O && db) {
+        const int o = e - O * I;
+        double s = 0.0;
+        for (int n = 0; n < N; ++n) s += (double)dy[(size_t)n * O + o];
+        db[o] = (float)s;
+    }
+}
+
+__global__ void softmax_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int O) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float* xr = x + (size_t)n * O;
+    float m = xr[0];
+    for (int o = 1; o < O; ++o) m = fmaxf(m, xr[o]);
+    float s = 0.f;
+    for (int o = 0; o < O; ++o) s += expf(xr[o] - m);
+    const float inv = 1.f / s;
+    for (int o = 0; o < O; ++o) y[(size_t)n * O + o] = expf(xr[o] - m) * inv;
+}
+
+__global__ void softmax_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                   float* __restrict__ dx, int N, int O) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float dot = 0.f;
+    for (int o = 0; o < O; ++o) dot = fmaf(dy[(size_t)n * O + o], y[(size_t)n * O + o], dot);
+    for (int o = 0; o < O; ++o)
+        dx[(size_t)n * O + o] = y[(size_t)n * O + o] * (dy[(size_t)n * O + o] - dot);
+}
+
+}  // namespace
+
+extern "C" int step_pool_fwd(const float* x, float* feat, int N, int C, int inner, void* stream) {
+    STEP_REQUIRE(x && feat && N > 0 && C > 0 && inner > 0 && (inner % 4) == 0,
+                 "step_pool_fwd: bad args N=%d C=%d inner=%d", N, C, inner);
+    const int NC = N * C;
+    hipLaunchKernelGGL(pool_fwd_kernel, dim3(step::ceil_div(NC, 4)), dim3(256), 0, (hipStream_t)stream,
+                       x, feat, NC, inner);
+    return step::check_launch("step_pool_fwd");
+}
+
+extern "C" int step_pool_bwd(const float* dfeat, float* dx, int N, int C, int inner, void* stream) {
+    STEP_REQUIRE(dfeat && dx && N > 0 && C > 0 && inner > 0, "step_pool_bwd: bad args");
+    const size_t total = (size_t)N * C * inner;
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(pool_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dfeat,
+                       dx, total, inner);
+    return step::check_launch("step_pool_bwd");
+}
+
+extern "C" int step_dense_fwd(const float* x, const float* w, const float* b, int w_transposed,
+                              float* y, int N, int I, int O, void* stream) {
+    STEP_REQUIRE(x && w && y && N > 0 && I > 0 && O > 0, "step_dense_fwd: bad args");
+    hipLaunchKernelGGL(dense_fwd_kernel, dim3(step::ceil_div(N * O, 128)), dim3(128), 0,
+                       (hipStream_t)stream, x, w, b, w_transposed, y, N, I, O);
+    return step::check_launch("step_dense_fwd");
+}
+
+extern "C" int step_dense_bwd(const float* dy, const float* x, const float* w, int w_transposed,
+                              float* dx, float* dw, float* db, int N, int I, int O, void* stream) {
+    STEP_REQUIRE(dy && x && w && N > 0 && I > 0 && O > 0, "step_dense_bwd: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    if (dx)
+        hipLaunchKernelGGL(dense_bwd_dx_kernel, dim3(step::ceil_div(N * I, 128)), dim3(128), 0, st, dy,
+                           w, w_transposed, dx, N, I, O);
+    if (dw || db)
+        hipLaunchKernelGGL(dense_bwd_dw_kernel, dim3(step::ceil_div(O * I + O, 128)), dim3(128), 0, st,
+                           dy, x, w_transposed, dw, db, N, I, O);
+    return step::check_launch("step_dense_bwd");
+}
+
+extern "C" int step_softmax_fwd(const float* x, float* y, int N, int O, void* stream) {
+    STEP_REQUIRE(x && y && N > 0 && O > 0, "step_softmax_fwd: bad args");
+    hipLaunchKernelGGL(softmax_fwd_kernel, dim3(step::ceil_div(N, 128)), dim3(128), 0,
+                       (hipStream_t)stream, x, y, N, O);
+    return step::check_launch("step_softmax_fwd");
+}
+
+extern "C" int step_softmax_bwd(const float* dy, const float* y, float* dx, int N, int O,
+                                void* stream) {
+    STEP_REQUIRE(dy && y && dx && N > 0 && O > 0, "step_softmax_bwd: bad args");
+    hipLaunchKernelGGL(softmax_bwd_kernel, dim3(step::ceil_div(N, 128)), dim3(128), 0,
+                       (hipStream_t)stream, dy, y, dx, N, O);
+    return step::check_launch("step_softmax_bwd");
+}

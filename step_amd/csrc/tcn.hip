@@ -1,0 +1,358 @@
+// Temporal (Kt x 1) convolution of the ST-GCN block as an fp32 MFMA implicit GEMM.
+//
+// Replaces tcn[2] = Conv2d(C,C,(Kt,1),(s,1),((Kt-1)//2,0)) of the reference
+// (classifier_stgcn_real_only/net/classifier.py:156-162), its ConvTranspose2d twin
+// (generator_cvae/net/CVAE_stgcn.py:359-365) and the input gradients of both.
+//
+// One generic form covers all four:
+//   out[n, c, PH*rho + ph, v] = epi( SUM_ci SUM_jj wp[ci][jj][ph*Cpad + c] *
+//                                    pre(in[n, ci, S*rho + jj - padL, v]) )
+// GEMM view (per sequence n): M = PH*Cpad output rows, N = (rho, v) positions,
+// K = Cin * 2*KS taps.  Because v (16 joints) is the innermost axis, the flattened
+// (t, v) axis makes the temporal convolution a 1-D correlation with dilation 16, so the
+// B operand of tap jj is just the LDS-resident input strip of channel ci shifted by jj
+// rows.  With v_mfma_f32_32x32x2_f32 a column tile is 2 output rows x 16 joints and one
+// k-step is a pair of adjacent taps; the B register of (column tile i, tap pair m)
+// depends only on i+m (stride 1) or 2i+m (stride 2, even/odd row planes), so each wave
+// keeps a sliding window of B registers and re-uses every LDS read NT times.
+//
+// Block = MW x NW waves: MW 32-row M tiles (all output channels) x NW column groups of
+// NT column tiles.  The K loop runs over input channels; per channel the block stages
+// the channel's input strip (BN1 + ReLU applied on the way in, padding rows zero) and
+// the channel's packed weights into double-buffered LDS, one barrier per channel.
+#include "common.h"
+
+namespace {
+
+struct TcnParams {
+    const float* in;
+    const float* in_scale;
+    const float* in_shift;
+    const float* wp;
+    const float* bias;
+    const float* out_scale;
+    const float* out_shift;
+    const float* res;
+    const float* res_scale;
+    const float* res_shift;
+    float* out;
+    int in_relu, out_relu;
+    int N, Cin, Cout, Cpad, PH, Tin, Tout, R, padL, nRB;
+};
+
+template <int NT, int KS, int STRIDE, int MW, int NW>
+struct TcnCfg {
+    static constexpr int NTHR = 64 * MW * NW;
+    static constexpr int RB = NW * NT * 2;                    // rho rows per block
+    static constexpr int ROWS = STRIDE * (RB - 1) + 2 * KS;   // staged input rows
+    static constexpr int STRIP = ROWS * 16;                   // floats
+    static constexpr int PLANE = (ROWS / 2) * 16;             // stride 2: even | odd rows
+    static constexpr int MPAD = 32 * MW;
+    static constexpr int WCH = 2 * KS * MPAD;                 // packed weights of 1 channel
+    static constexpr int NB = (STRIDE == 1) ? (NT + KS - 1) : (2 * (NT - 1) + KS);
+    static constexpr int SF4 = (ROWS * 4 + NTHR - 1) / NTHR;  // float4 per thread
+    static constexpr int WF4 = (WCH / 4 + NTHR - 1) / NTHR;
+    static constexpr int BUF = STRIP + WCH;
+    static_assert(STRIDE == 1 || ROWS % 2 == 0, "planes");
+    static_assert(WCH % 4 == 0, "float4 weights");
+};
+
+template <int NT, int KS, int STRIDE, int MW, int NW>
+__global__ __launch_bounds__(64 * MW * NW) void tcn_conv_kernel(TcnParams p) {
+    using Cfg = TcnCfg<NT, KS, STRIDE, MW, NW>;
+    __shared__ __attribute__((aligned(16))) float smem[2 * Cfg::BUF];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int mw = wave / NW;
+    const int wn = wave % NW;
+    const int l31 = lane & 31;
+    const int half = lane >> 5;
+
+    const int n = blockIdx.x / p.nRB;
+    const int rho0 = (blockIdx.x % p.nRB) * Cfg::RB;
+    const int tin0 = STRIDE * rho0 - p.padL;                  // input row of strip row 0
+    const bool wave_live = (rho0 + 2 * wn * NT) < p.R;
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    float4 sreg[Cfg::SF4];
+    float4 wreg[Cfg::WF4];
+
+    auto load_regs = [&](int c) {
+        const float* src = p.in + ((size_t)n * p.Cin + c) * p.Tin * 16;
+        float sc = 1.f, sh = 0.f;
+        if (p.in_scale) { sc = p.in_scale[c]; sh = p.in_shift[c]; }
+#pragma unroll
+        for (int k = 0; k < Cfg::SF4; ++k) {
+            const int f = tid + k * Cfg::NTHR;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (f < Cfg::ROWS * 4) {
+                const int lr = f >> 2;
+                const int tin = tin0 + lr;
+                if (tin >= 0 && tin < p.Tin) {
+                    v = *reinterpret_cast<const float4*>(src + (size_t)tin * 16 + (f & 3) * 4);
+                    v.x = v.x * sc + sh; v.y = v.y * sc + sh;
+                    v.z = v.z * sc + sh; v.w = v.w * sc + sh;
+                    if (p.in_relu) {
+                        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f);
+                        v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                    }
+                }
+            }
+            sreg[k] = v;
+        }
+        const float* wsrc = p.wp + (size_t)c * Cfg::WCH;
+#pragma unroll
+        for (int k = 0; k < Cfg::WF4; ++k) {
+            const int f = tid + k * Cfg::NTHR;
+            if (f < Cfg::WCH / 4) wreg[k] = *reinterpret_cast<const float4*>(wsrc + f * 4);
+        }
+    };
+
+    auto store_lds = [&](float* buf) {
+#pragma unroll
+        for (int k = 0; k < Cfg::SF4; ++k) {
+            const int f = tid + k * Cfg::NTHR;
+            if (f < Cfg::ROWS * 4) {
+                const int lr = f >> 2;
+                int dst;
+                if (STRIDE == 1) dst = lr * 16 + (f & 3) * 4;
+                else dst = (lr & 1) * Cfg::PLANE + (lr >> 1) * 16 + (f & 3) * 4;
+                *reinterpret_cast<float4*>(buf + dst) = sreg[k];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < Cfg::WF4; ++k) {
+            const int f = tid + k * Cfg::NTHR;
+            if (f < Cfg::WCH / 4)
+                *reinterpret_cast<float4*>(buf + Cfg::STRIP + f * 4) = wreg[k];
+        }
+    };
+
+    auto compute = [&](const float* buf) {
+        const float* S = buf;
+        const float* W = buf + Cfg::STRIP + mw * 32 + l31 + half * Cfg::MPAD;
+        float b[Cfg::NB];
+        if (STRIDE == 1) {
+            const float* bs = S + (2 * wn * NT) * 16 + l31 + half * 16;
+#pragma unroll
+            for (int q = 0; q < Cfg::NB; ++q) b[q] = bs[q * 32];
+        } else {
+            const float* bs = S + half * Cfg::PLANE + (2 * wn * NT) * 16 + l31;
+#pragma unroll
+            for (int q = 0; q < Cfg::NB; ++q) b[q] = bs[q * 16];
+        }
+#pragma unroll
+        for (int m = 0; m < KS; ++m) {
+            const float a = W[2 * m * Cfg::MPAD];
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                const int q = (STRIDE == 1) ? (i + m) : (2 * i + m);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[q], acc[i], 0, 0, 0);
+            }
+        }
+    };
+
+    load_regs(0);
+    store_lds(smem);
+    __syncthreads();
+    for (int c = 0; c < p.Cin; ++c) {
+        float* cur = smem + (c & 1) * Cfg::BUF;
+        float* nxt = smem + ((c + 1) & 1) * Cfg::BUF;
+        const bool more = (c + 1) < p.Cin;
+        if (more) load_regs(c + 1);
+        if (wave_live) compute(cur);
+        if (more) store_lds(nxt);
+        __syncthreads();
+    }
+
+    if (!wave_live) return;
+    // epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const int v = l31 & 15;
+    const int trow = l31 >> 4;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = mw * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int ph = m / p.Cpad;
+        const int c = m - ph * p.Cpad;
+        if (c >= p.Cout || ph >= p.PH) continue;
+        const float bia = p.bias ? p.bias[c] : 0.f;
+        float osc = 1.f, osh = 0.f, rsc = 1.f, rsh = 0.f;
+        if (p.out_scale) { osc = p.out_scale[c]; osh = p.out_shift[c]; }
+        if (p.res && p.res_scale) { rsc = p.res_scale[c]; rsh = p.res_shift[c]; }
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            const int rho = rho0 + 2 * (wn * NT + i) + trow;
+            const int t = p.PH * rho + ph;
+            if (rho < p.R && t < p.Tout) {
+                const size_t o = (((size_t)n * p.Cout + c) * p.Tout + t) * 16 + v;
+                float val = (acc[i][r] + bia) * osc + osh;
+                if (p.res) val += p.res[o] * rsc + rsh;
+                if (p.out_relu) val = fmaxf(val, 0.f);
+                p.out[o] = val;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ weight re-layout
+struct PackGeom {
+    int cin_g, cout_g, cpad, ph, ks, padL, stride_g;
+};
+
+// geometry of the generic form for each pack_mode (see step_hip.h)
+bool pack_geom(int Co, int Ci, int Kt, int stride, int mode, PackGeom* g) {
+    if (Kt < 1 || (Kt & 1) == 0) return false;
+    const int p = (Kt - 1) / 2;
+    g->ph = 1;
+    g->stride_g = 1;
+    g->ks = (Kt + 1) / 2;
+    g->padL = p;                               // Kt-1-p == p for odd Kt
+    switch (mode) {
+        case 0: g->cin_g = Ci; g->cout_g = Co; g->stride_g = stride; break;
+        case 1: if (stride != 1) return false; g->cin_g = Ci; g->cout_g = Co; break;
+        case 2:
+            g->cin_g = Co; g->cout_g = Ci;
+            if (stride == 2) {
+                g->ph = 2;
+                g->padL = p / 2;
+                int slots = 0;
+                for (int ph = 0; ph < 2; ++ph) {
+                    const int jmin = (ph + p) & 1;
+                    const int s = (ph + p + 2 * g->padL - jmin) / 2 + 1;
+                    slots = s > slots ? s : slots;
+                }
+                g->ks = (slots + 1) / 2;
+            } else if (stride != 1) return false;
+            break;
+        case 3: if (stride != 1) return false; g->cin_g = Co; g->cout_g = Ci; break;
+        default: return false;
+    }
+    if (stride != 1 && stride != 2) return false;
+    g->cpad = step::round_up(g->cout_g, 32);
+    return true;
+}
+
+__global__ void tcn_pack_kernel(const float* __restrict__ w, float* __restrict__ wp, int Co,
+                                int Ci, int Kt, int stride, int mode, PackGeom g) {
+    const int mpad = g.ph * g.cpad;
+    const int total = g.cin_g * 2 * g.ks * mpad;
+    const int p = (Kt - 1) / 2;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const int m = e % mpad;
+        const int jj = (e / mpad) % (2 * g.ks);
+        const int cg = e / (mpad * 2 * g.ks);          // GEMM input channel
+        const int ph = m / g.cpad;
+        const int c = m % g.cpad;                      // GEMM output channel
+        float val = 0.f;
+        if (c < g.cout_g) {
+            if (mode == 0) {                           // w (Co,Ci,Kt): cg = ci, c = co
+                if (jj < Kt) val = w[((size_t)c * Ci + cg) * Kt + jj];
+            } else if (mode == 1) {                    // w (Ci,Co,Kt): cg = ci, c = co
+                if (jj < Kt) val = w[((size_t)cg * Co + c) * Kt + (Kt - 1 - jj)];
+            } else if (mode == 2) {                    // w (Co,Ci,Kt): cg = co, c = ci
+                int j;
+                if (stride == 1) j = Kt - 1 - jj;
+                else j = ph + p + 2 * g.padL - 2 * jj;
+                if (j >= 0 && j < Kt) val = w[((size_t)cg * Ci + c) * Kt + j];
+            } else {                                   // w (Ci,Co,Kt): cg = co, c = ci
+                if (jj < Kt) val = w[((size_t)c * Co + cg) * Kt + jj];
+            }
+        }
+        wp[e] = val;
+    }
+}
+
+template <int NT, int KS, int STRIDE, int MW, int NW>
+int launch_tcn(const TcnParams& p, hipStream_t st) {
+    using Cfg = TcnCfg<NT, KS, STRIDE, MW, NW>;
+    TcnParams q = p;
+    q.nRB = step::ceil_div(p.R, Cfg::RB);
+    const long long blocks = (long long)p.N * q.nRB;
+    if (blocks <= 0 || blocks > 0x7fffffffLL) {
+        step::set_error("step_tcn_conv: grid of %lld blocks out of range", blocks);
+        return STEP_ERR_ARG;
+    }
+    hipLaunchKernelGGL((tcn_conv_kernel<NT, KS, STRIDE, MW, NW>), dim3((unsigned)blocks),
+                       dim3(Cfg::NTHR), 0, st, q);
+    return step::check_launch("step_tcn_conv");
+}
+
+}  // namespace
+
+extern "C" size_t step_tcn_packed_elems(int Co, int Ci, int Kt, int stride, int pack_mode) {
+    PackGeom g;
+    if (Co < 1 || Ci < 1 || !pack_geom(Co, Ci, Kt, stride, pack_mode, &g)) return 0;
+    return (size_t)g.cin_g * 2 * g.ks * g.ph * g.cpad;
+}
+
+extern "C" int step_tcn_pack_weight(const float* w, float* wp, int Co, int Ci, int Kt, int stride,
+                                    int pack_mode, void* stream) {
+    PackGeom g;
+    STEP_REQUIRE(w && wp, "step_tcn_pack_weight: null pointer");
+    STEP_REQUIRE(Co >= 1 && Ci >= 1 && pack_geom(Co, Ci, Kt, stride, pack_mode, &g),
+                 "step_tcn_pack_weight: unsupported Co=%d Ci=%d Kt=%d stride=%d mode=%d", Co, Ci, Kt,
+                 stride, pack_mode);
+    const int total = g.cin_g * 2 * g.ks * g.ph * g.cpad;
+    const int blocks = step::ceil_div(total, 256) < 1024 ? step::ceil_div(total, 256) : 1024;
+    hipLaunchKernelGGL(tcn_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, wp, Co, Ci,
+                       Kt, stride, pack_mode, g);
+    return step::check_launch("step_tcn_pack_weight");
+}
+
+extern "C" int step_tcn_conv(const float* in, const float* in_scale, const float* in_shift,
+                             int in_relu, const float* wp, const float* bias,
+                             const float* out_scale, const float* out_shift, const float* res,
+                             const float* res_scale, const float* res_shift, int out_relu,
+                             float* out, int N, int Ci, int Co, int Tin, int Tout, int Kt,
+                             int stride, int pack_mode, void* stream) {
+    PackGeom g;
+    STEP_REQUIRE(in && wp && out, "step_tcn_conv: null pointer");
+    STEP_REQUIRE(N >= 1 && Ci >= 1 && Co >= 1 && Tin >= 1 && Tout >= 1,
+                 "step_tcn_conv: bad shape N=%d Ci=%d Co=%d Tin=%d Tout=%d", N, Ci, Co, Tin, Tout);
+    STEP_REQUIRE(pack_geom(Co, Ci, Kt, stride, pack_mode, &g),
+                 "step_tcn_conv: unsupported Kt=%d stride=%d mode=%d", Kt, stride, pack_mode);
+    STEP_REQUIRE(Tout == (Tin - 1) / stride + 1, "step_tcn_conv: Tout=%d != (Tin-1)/stride+1 (Tin=%d)",
+                 Tout, Tin);
+    STEP_REQUIRE((in_scale == nullptr) == (in_shift == nullptr) &&
+                     (out_scale == nullptr) == (out_shift == nullptr) &&
+                     (res_scale == nullptr) == (res_shift == nullptr),
+                 "step_tcn_conv: scale/shift must come in pairs");
+    TcnParams p{};
+    p.in = in; p.in_scale = in_scale; p.in_shift = in_shift; p.in_relu = in_relu;
+    p.wp = wp; p.bias = bias; p.out_scale = out_scale; p.out_shift = out_shift;
+    p.res = res; p.res_scale = res_scale; p.res_shift = res_shift; p.out_relu = out_relu;
+    p.out = out; p.N = N; p.Cin = g.cin_g; p.Cout = g.cout_g; p.Cpad = g.cpad; p.PH = g.ph;
+    p.padL = g.padL;
+    const bool dgrad = pack_mode >= 2;
+    p.Tin = dgrad ? Tout : Tin;                 // rows of the tensor being read
+    p.Tout = dgrad ? Tin : Tout;                // rows of the tensor being written
+    p.R = step::ceil_div(p.Tout, g.ph);
+    const int mw = g.ph * g.cpad / 32;
+    const int key = g.ks * 100 + g.stride_g * 10 + mw;
+    hipStream_t st = (hipStream_t)stream;
+    switch (key) {
+        case 3811: return launch_tcn<5, 38, 1, 1, 4>(p, st);
+        case 3812: return launch_tcn<5, 38, 1, 2, 2>(p, st);
+        case 3821: return launch_tcn<5, 38, 2, 1, 4>(p, st);
+        case 3822: return launch_tcn<5, 38, 2, 2, 2>(p, st);
+        case 1912: return launch_tcn<5, 19, 1, 2, 2>(p, st);
+        case 1914: return launch_tcn<5, 19, 1, 4, 2>(p, st);
+        case 511: return launch_tcn<5, 5, 1, 1, 4>(p, st);
+        case 512: return launch_tcn<5, 5, 1, 2, 2>(p, st);
+        case 521: return launch_tcn<5, 5, 2, 1, 4>(p, st);
+        case 522: return launch_tcn<5, 5, 2, 2, 2>(p, st);
+        case 312: return launch_tcn<5, 3, 1, 2, 2>(p, st);
+        case 314: return launch_tcn<5, 3, 1, 4, 2>(p, st);
+        default: break;
+    }
+    step::set_error("step_tcn_conv: no kernel for Kt=%d stride=%d channels=%d (ks=%d mw=%d)", Kt,
+                    stride, g.cout_g, g.ks, mw);
+    return STEP_ERR_ARG;
+}

@@ -1,0 +1,194 @@
+"""GPU: every HIP entry point against the CPU oracle on seeded inputs (fp32, tolerance 1e-4
+relative to the tensor's max magnitude unless stated: north_star's fp32 bar)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import stgcn, graph_adjacency
+from tests.util import assert_close, assert_grad_close
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def A_spatial(dense=False, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    A = torch.tensor(graph_adjacency("spatial"), dtype=torch.float32)
+    if dense:
+        return torch.rand(3, 16, 16, generator=g) - 0.3
+    return A * (torch.rand(3, 16, 16, generator=g) * 2 - 0.5)
+
+
+# --------------------------------------------------------------------------- tcn
+@pytest.mark.parametrize("C,Co,Kt,stride,T,N", [
+    (32, 32, 75, 1, 40, 2), (64, 64, 75, 1, 23, 2), (64, 64, 75, 2, 41, 2), (32, 32, 75, 2, 30, 1),
+    (3, 3, 75, 1, 20, 2), (32, 32, 9, 1, 50, 2), (64, 64, 9, 2, 37, 2), (64, 64, 75, 1, 240, 1),
+])
+def test_tcn_forward_and_epilogue(C, Co, Kt, stride, T, N):
+    from step_amd import ops
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(N, C, T, 16, generator=g)
+    w = torch.randn(Co, C, Kt, 1, generator=g) * 0.05
+    b = torch.randn(Co, generator=g)
+    sc, sh = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3
+    To = (T - 1) // stride + 1
+    a = torch.relu(x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    ref = stgcn.temporal_conv(a, w, b, stride)
+    d = dev()
+    wp = ops.tcn_pack(w.to(d), Co, C, Kt, stride, 0)
+    out = ops.tcn_conv(x.to(d), sc.to(d), sh.to(d), True, wp, b.to(d), None, None, None, None, None,
+                       False, N, C, Co, T, To, Kt, stride, 0)
+    assert_close(out, ref, TOL, "tcn raw")
+    # fused eval epilogue: BN2 affine + residual affine + ReLU
+    osc, osh = torch.rand(Co, generator=g) + 0.5, torch.randn(Co, generator=g) * 0.2
+    res = torch.randn(N, Co, To, 16, generator=g)
+    rsc, rsh = torch.rand(Co, generator=g) + 0.5, torch.randn(Co, generator=g) * 0.2
+    v = lambda t: t.view(1, -1, 1, 1)
+    ref2 = torch.relu(ref * v(osc) + v(osh) + res * v(rsc) + v(rsh))
+    out2 = ops.tcn_conv(x.to(d), sc.to(d), sh.to(d), True, wp, b.to(d), osc.to(d), osh.to(d),
+                        res.to(d), rsc.to(d), rsh.to(d), True, N, C, Co, T, To, Kt, stride, 0)
+    assert_close(out2, ref2, TOL, "tcn fused")
+
+
+@pytest.mark.parametrize("C,Kt,stride,T,N", [(32, 75, 1, 33, 2), (64, 75, 2, 41, 2), (64, 75, 2, 40, 1),
+                                             (32, 75, 2, 21, 2), (64, 9, 2, 30, 2), (3, 75, 1, 16, 2)])
+def test_tcn_dgrad_and_wgrad(C, Kt, stride, T, N):
+    from step_amd import ops
+    g = torch.Generator().manual_seed(2)
+    y = torch.randn(N, C, T, 16, generator=g)
+    w = (torch.randn(C, C, Kt, 1, generator=g) * 0.05).requires_grad_(True)
+    b = torch.randn(C, generator=g).requires_grad_(True)
+    sc, sh = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3
+    To = (T - 1) // stride + 1
+    a = torch.relu(y * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)).requires_grad_(True)
+    u = stgcn.temporal_conv(a, w, b, stride)
+    du = torch.randn(u.shape, generator=g)
+    u.backward(du)
+    d = dev()
+    wpd = ops.tcn_pack(w.detach().to(d), C, C, Kt, stride, 2)
+    da = ops.tcn_conv(du.to(d), None, None, False, wpd, None, None, None, None, None, None, False,
+                      N, C, C, T, To, Kt, stride, 2)
+    assert_close(da, a.grad, TOL, "dgrad")
+    dw, db = ops.tcn_wgrad(du.to(d), y.to(d), sc.to(d), sh.to(d), True, N, C, C, T, To, Kt, stride,
+                           False, w.shape)
+    assert_close(dw, w.grad, TOL, "wgrad")
+    assert_close(db, b.grad, TOL, "bgrad")
+
+
+@pytest.mark.parametrize("Ci,Co,Kt,T", [(32, 32, 75, 24), (32, 64, 9, 30), (64, 3, 75, 20)])
+def test_tcn_transposed(Ci, Co, Kt, T):
+    """ConvTranspose2d twin (CVAE_stgcn.py:359-365): forward, dgrad, wgrad.  In st_gctn the
+    temporal conv is always square (Co x Co); Ci here is ignored except as a label."""
+    from step_amd import ops
+    C, N = Co, 2
+    g = torch.Generator().manual_seed(3)
+    a = torch.randn(N, C, T, 16, generator=g).requires_grad_(True)
+    w = (torch.randn(C, C, Kt, 1, generator=g) * 0.05).requires_grad_(True)
+    b = torch.randn(C, generator=g).requires_grad_(True)
+    u = stgcn.temporal_conv(a, w, b, 1, transposed=True)
+    du = torch.randn(u.shape, generator=g)
+    u.backward(du)
+    d = dev()
+    wp = ops.tcn_pack(w.detach().to(d), C, C, Kt, 1, 1)
+    out = ops.tcn_conv(a.detach().to(d), None, None, False, wp, b.detach().to(d), None, None, None, None,
+                       None, False, N, C, C, T, T, Kt, 1, 1)
+    assert_close(out, u, TOL, "convT fwd")
+    wpd = ops.tcn_pack(w.detach().to(d), C, C, Kt, 1, 3)
+    da = ops.tcn_conv(du.to(d), None, None, False, wpd, None, None, None, None, None, None, False,
+                      N, C, C, T, T, Kt, 1, 3)
+    assert_close(da, a.grad, TOL, "convT dgrad")
+    dw, db = ops.tcn_wgrad(du.to(d), a.detach().to(d), None, None, False, N, C, C, T, T, Kt, 1, True, w.shape)
+    assert_close(dw, w.grad, TOL, "convT wgrad")
+
+
+# --------------------------------------------------------------------------- gcn
+@pytest.mark.parametrize("Ci,Co,T,N,transposed,dense", [
+    (3, 32, 20, 3, False, False), (32, 64, 17, 2, False, False), (64, 64, 9, 2, False, False),
+    (7, 64, 12, 2, False, False), (64, 3, 11, 2, True, False), (32, 32, 8, 2, True, False),
+    (32, 64, 10, 2, False, True), (64, 32, 24, 1, False, False),
+])
+def test_gcn_fwd_bwd(Ci, Co, T, N, transposed, dense):
+    from step_amd.net.utils.tgcn import GcnFn
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(N, Ci, T, 16, generator=g)
+    A = A_spatial(dense)
+    w = torch.randn((Ci, 3 * Co, 1, 1) if transposed else (3 * Co, Ci, 1, 1), generator=g) * 0.2
+    b = torch.randn(3 * Co, generator=g)
+    leaves = [t.clone().requires_grad_(True) for t in (x, A, w, b)]
+    y = stgcn.conv_temporal_graphical(leaves[0], leaves[1], leaves[2], leaves[3], transposed)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    d = dev()
+    gl = [t.clone().to(d).requires_grad_(True) for t in (x, A, w, b)]
+    nnz = 16 if dense else 3
+    yg = GcnFn.apply(gl[0], gl[1], gl[2], gl[3], transposed, nnz)
+    assert_close(yg, y, TOL, "gcn y")
+    yg.backward(gy.to(d))
+    assert_close(gl[0].grad, leaves[0].grad, TOL, "dx")
+    assert_close(gl[2].grad, leaves[2].grad, TOL, "dw")
+    assert_close(gl[3].grad, leaves[3].grad, TOL, "db")
+    supp = (A != 0).float()
+    assert_close(gl[1].grad.cpu() * supp, leaves[1].grad * supp, TOL, "dA on supp(A)")
+
+
+# ---------------------------------------------------------------------------- bn
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("N,C,T", [(3, 5, 7), (300, 3, 11), (2, 64, 40)])
+def test_bn_train_prepare_and_backward(mode, N, C, T):
+    from step_amd import ops
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randn(N, C, T, 16, generator=g) * 2 + 0.7)
+    G = C * 16 if mode else C
+    gamma, beta = torch.rand(G, generator=g) + 0.5, torch.randn(G, generator=g)
+    P = {"bn.weight": gamma.clone().requires_grad_(True), "bn.bias": beta.clone().requires_grad_(True),
+         "bn.running_mean": torch.randn(G, generator=g), "bn.running_var": torch.rand(G, generator=g) + 0.5}
+    rm0, rv0 = P["bn.running_mean"].clone(), P["bn.running_var"].clone()
+    xr = x.clone().requires_grad_(True)
+    if mode:
+        yr = stgcn.data_bn(xr, P, "bn", True)
+    else:
+        yr = stgcn.bn2d(xr, P, "bn", True)
+    out_ref = torch.relu(yr)
+    gy = torch.randn(out_ref.shape, generator=g)
+    out_ref.backward(gy)
+    d = dev()
+    rm, rv = rm0.to(d), rv0.to(d)
+    mean, invstd, scale, shift = ops.bn_train_prepare(x.to(d), mode, gamma.to(d), beta.to(d), rm, rv)
+    assert_close(rm, P["bn.running_mean"], 1e-5, "running_mean")
+    assert_close(rv, P["bn.running_var"], 1e-5, "running_var")
+    out = ops.affine_act(x.to(d), scale, shift, None, None, None, True, mode)
+    assert_close(out, out_ref, TOL, "bn+relu")
+    dx, dg, db = ops.bn_backward(gy.to(d), x.to(d), None, scale, shift, 2, mean, invstd, gamma.to(d), True, mode)
+    assert_close(dx, xr.grad, 2e-4, "dx")
+    assert_close(dg, P["bn.weight"].grad, 2e-4, "dgamma")
+    assert_close(db, P["bn.bias"].grad, 2e-4, "dbeta")
+    # mask from a saved output tensor gives the same thing
+    dx2, _, _ = ops.bn_backward(gy.to(d), x.to(d), out, None, None, 1, mean, invstd, gamma.to(d), True, mode)
+    assert torch.equal(dx, dx2)
+
+
+def test_heads():
+    from step_amd import ops
+    g = torch.Generator().manual_seed(6)
+    d = dev()
+    x = torch.randn(5, 64, 30, 16, generator=g)
+    xg = x.clone().to(d).requires_grad_(True)
+    f = ops.PoolFn.apply(xg)
+    assert_close(f, x.mean(dim=(2, 3)), 1e-5, "pool")
+    w = torch.randn(4, 64, 1, 1, generator=g)
+    b = torch.randn(4, generator=g)
+    wg, bg = w.clone().to(d).requires_grad_(True), b.clone().to(d).requires_grad_(True)
+    p = ops.SoftmaxFn.apply(ops.DenseFn.apply(f, wg, bg, False))
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    pr = torch.softmax(xr.mean(dim=(2, 3)) @ wr.view(4, 64).t() + br, dim=1)
+    assert_close(p, pr, 1e-5, "softmax")
+    lab = torch.tensor([0, 1, 2, 3, 1])
+    F.cross_entropy(pr, lab).backward()
+    F.cross_entropy(p, lab.to(d)).backward()
+    assert_close(xg.grad, xr.grad, 1e-4, "dx")
+    assert_close(wg.grad, wr.grad, 1e-4, "dw")
+    assert_close(bg.grad, br.grad, 1e-4, "db")
