@@ -166,6 +166,15 @@ int step_dense_fwd(const float* x, const float* w, const float* b, int w_transpo
                    float* y, int N, int I, int O, void* stream);
 int step_dense_bwd(const float* dy, const float* x, const float* w, int w_transposed,
                    float* dx, float* dw, float* db, int N, int I, int O, void* stream);
+/* nn.BatchNorm1d on a (N, G) matrix - `data_bn2` of the hybrid head,
+ * classifier_hybrid/net/classifier.py:46,83.  Emits mean/invstd (batch or running).        */
+int step_bn_rows_fwd(const float* x, const float* gamma, const float* beta,
+                     float* running_mean, float* running_var, int training,
+                     float momentum, float eps, float* y, float* mean, float* invstd,
+                     int N, int G, void* stream);
+int step_bn_rows_bwd(const float* dy, const float* x, const float* mean, const float* invstd,
+                     const float* gamma, int training, float* dx, float* dgamma, float* dbeta,
+                     int N, int G, void* stream);
 /* F.softmax(x, dim=1) classifier.py:87 and its backward */
 int step_softmax_fwd(const float* x, float* y, int N, int O, void* stream);
 int step_softmax_bwd(const float* dy, const float* y, float* dx, int N, int O, void* stream);

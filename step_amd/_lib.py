@@ -40,6 +40,8 @@ SIGNATURES = {
     "step_pool_bwd": (I, [P, P, I, I, I, P]),
     "step_dense_fwd": (I, [P, P, P, I, P, I, I, I, P]),
     "step_dense_bwd": (I, [P, P, P, I, P, P, P, I, I, I, P]),
+    "step_bn_rows_fwd": (I, [P, P, P, P, P, I, F, F, P, P, P, I, I, P]),
+    "step_bn_rows_bwd": (I, [P, P, P, P, P, I, P, P, P, I, I, P]),
     "step_softmax_fwd": (I, [P, P, I, I, P]),
     "step_softmax_bwd": (I, [P, P, P, I, I, P]),
 }

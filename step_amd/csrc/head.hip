@@ -107,7 +107,84 @@ __global__ void softmax_bwd_kernel(const float* __restrict__ dy, const float* __
         dx[(size_t)n * O + o] = y[(size_t)n * O + o] * (dy[(size_t)n * O + o] - dot);
 }
 
+// BatchNorm1d on a (N, G) matrix: one wavefront per column g (the hybrid head's data_bn2)
+__global__ __launch_bounds__(64) void bn_rows_fwd_kernel(const float* __restrict__ x,
+                                                         const float* gamma, const float* beta,
+                                                         float* running_mean, float* running_var,
+                                                         int training, float momentum, float eps,
+                                                         float* __restrict__ y, float* mean_out,
+                                                         float* invstd_out, int N, int G) {
+    const int g = blockIdx.x, lane = threadIdx.x;
+    float m, inv;
+    if (training) {
+        float s = 0.f, ss = 0.f;
+        for (int n = lane; n < N; n += 64) { const float v = x[(size_t)n * G + g]; s += v; ss += v * v; }
+        s = wave_sum(s); ss = wave_sum(ss);
+        s = __shfl(s, 0, 64); ss = __shfl(ss, 0, 64);
+        m = s / N;
+        float var = ss / N - m * m;
+        var = var > 0.f ? var : 0.f;
+        inv = 1.f / sqrtf(var + eps);
+        if (lane == 0 && running_mean) {
+            const float unb = N > 1 ? var * N / (N - 1) : var;
+            running_mean[g] = (1.f - momentum) * running_mean[g] + momentum * m;
+            running_var[g] = (1.f - momentum) * running_var[g] + momentum * unb;
+        }
+    } else {
+        m = running_mean[g];
+        inv = 1.f / sqrtf(running_var[g] + eps);
+    }
+    if (lane == 0) { mean_out[g] = m; invstd_out[g] = inv; }
+    const float sc = (gamma ? gamma[g] : 1.f) * inv, sh = (beta ? beta[g] : 0.f) - m * sc;
+    for (int n = lane; n < N; n += 64) y[(size_t)n * G + g] = x[(size_t)n * G + g] * sc + sh;
+}
+
+__global__ __launch_bounds__(64) void bn_rows_bwd_kernel(const float* __restrict__ dy,
+                                                         const float* __restrict__ x,
+                                                         const float* mean, const float* invstd,
+                                                         const float* gamma, int training,
+                                                         float* __restrict__ dx, float* dgamma,
+                                                         float* dbeta, int N, int G) {
+    const int g = blockIdx.x, lane = threadIdx.x;
+    const float m = mean[g], inv = invstd[g], ga = gamma ? gamma[g] : 1.f;
+    float s1 = 0.f, s2 = 0.f;
+    for (int n = lane; n < N; n += 64) {
+        const float d = dy[(size_t)n * G + g];
+        s1 += d; s2 += d * (x[(size_t)n * G + g] - m) * inv;
+    }
+    s1 = wave_sum(s1); s2 = wave_sum(s2);
+    s1 = __shfl(s1, 0, 64); s2 = __shfl(s2, 0, 64);
+    if (lane == 0) { if (dgamma) dgamma[g] = s2; if (dbeta) dbeta[g] = s1; }
+    if (!dx) return;
+    for (int n = lane; n < N; n += 64) {
+        const float d = dy[(size_t)n * G + g];
+        float r = d;
+        if (training) r = d - s1 / N - (x[(size_t)n * G + g] - m) * inv * s2 / N;
+        dx[(size_t)n * G + g] = ga * inv * r;
+    }
+}
+
 }  // namespace
+
+extern "C" int step_bn_rows_fwd(const float* x, const float* gamma, const float* beta,
+                                float* running_mean, float* running_var, int training,
+                                float momentum, float eps, float* y, float* mean, float* invstd,
+                                int N, int G, void* stream) {
+    STEP_REQUIRE(x && y && mean && invstd && N > 0 && G > 0, "step_bn_rows_fwd: bad args");
+    STEP_REQUIRE(training || (running_mean && running_var), "step_bn_rows_fwd: eval needs running stats");
+    hipLaunchKernelGGL(bn_rows_fwd_kernel, dim3(G), dim3(64), 0, (hipStream_t)stream, x, gamma, beta,
+                       running_mean, running_var, training, momentum, eps, y, mean, invstd, N, G);
+    return step::check_launch("step_bn_rows_fwd");
+}
+
+extern "C" int step_bn_rows_bwd(const float* dy, const float* x, const float* mean,
+                                const float* invstd, const float* gamma, int training, float* dx,
+                                float* dgamma, float* dbeta, int N, int G, void* stream) {
+    STEP_REQUIRE(dy && x && mean && invstd && N > 0 && G > 0, "step_bn_rows_bwd: bad args");
+    hipLaunchKernelGGL(bn_rows_bwd_kernel, dim3(G), dim3(64), 0, (hipStream_t)stream, dy, x, mean,
+                       invstd, gamma, training, dx, dgamma, dbeta, N, G);
+    return step::check_launch("step_bn_rows_bwd");
+}
 
 extern "C" int step_pool_fwd(const float* x, float* feat, int N, int C, int inner, void* stream) {
     STEP_REQUIRE(x && feat && N > 0 && C > 0 && inner > 0 && (inner % 4) == 0,

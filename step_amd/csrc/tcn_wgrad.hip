@@ -198,6 +198,7 @@ bool wg_geom(int N, int Ci, int Co, int Kt, int stride, WgGeom* g) {
     while ((rs & 31) != (Kt & 31)) ++rs;               // channel stride == Kt (mod 32)
     g->RS = rs;
     g->NCH = (g->qb + Kt - 1) / Kt + 1;
+    if (g->NCH > Ci) g->NCH = Ci;                      // a block never touches more than Ci channels
     g->VS = g->NCH * g->RS + 1;
     g->lds = ((size_t)32 * g->mw * WG_DS + (size_t)16 * g->VS) * 4;
     g->ws = ((size_t)g->nsplit * Co * Q + (size_t)g->nsplit * Co) * 4;

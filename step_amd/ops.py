@@ -165,8 +165,7 @@ class StGcnBlockFn(torch.autograd.Function):
         Co, Kt, st = s.Co, s.Kt, s.stride
         To = (T - 1) // st + 1
         K = A_eff.shape[0]
-        need_grad = torch.is_grad_enabled() and (
-            x.requires_grad or A_eff.requires_grad or any(p.requires_grad for p in params))
+        need_grad = any(ctx.needs_input_grad)       # all False under torch.no_grad()
         dev = x.device
 
         # data_bn statistics (training) or running stats (eval); applied inside the gcn load
@@ -214,7 +213,7 @@ class StGcnBlockFn(torch.autograd.Function):
             ctx.nparams = len(params)
             ctx.save_for_backward(x, A_eff, y, u, r, out, gcn_w, gcn_b, tcn_w, res_w, bn1_w, bn2_w, bnr_w,
                                   dbn_w, m0, i0, s0, h0, m1, i1, s1, h1, m2, i2, s2, h2, mr, ir, sr, hr)
-            ctx.x_needs_grad = x.requires_grad
+            ctx.x_needs_grad = ctx.needs_input_grad[2]
         return out
 
     @staticmethod
@@ -359,4 +358,33 @@ class DataBnFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, mean, invstd, weight = ctx.saved_tensors
         dx, dg, db = bn_backward(_f32(dy), x, None, None, None, 0, mean, invstd, weight, ctx.training, 1)
+        return None, None, dx, dg, db
+
+
+class BnRowsFn(torch.autograd.Function):
+    """nn.BatchNorm1d on (N, G): data_bn2 of the hybrid head, classifier_hybrid/net/classifier.py:83"""
+
+    @staticmethod
+    def forward(ctx, bn, training, x, weight, bias):
+        x = _f32(x)
+        N, G = x.shape
+        y = torch.empty_like(x)
+        mean = torch.empty(G, dtype=torch.float32, device=x.device)
+        invstd = torch.empty_like(mean)
+        _lib.call("step_bn_rows_fwd", x, weight, bias, bn.running_mean, bn.running_var, int(training),
+                  BN_MOMENTUM, BN_EPS, y, mean, invstd, N, G)
+        if training:
+            bn.num_batches_tracked += 1
+        ctx.training = training
+        ctx.save_for_backward(x, mean, invstd, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mean, invstd, weight = ctx.saved_tensors
+        N, G = x.shape
+        dx = torch.empty_like(x)
+        dg = torch.empty(G, dtype=torch.float32, device=x.device)
+        db = torch.empty_like(dg)
+        _lib.call("step_bn_rows_bwd", _f32(dy), x, mean, invstd, weight, int(ctx.training), dx, dg, db, N, G)
         return None, None, dx, dg, db
