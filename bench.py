@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""bench.py - ST-GCN fwd+bwd sequences/s on MI355X (BASELINE.json's metric).
+
+A "step" is one training iteration of the hot path over one batch of synthetic skeletons that
+is already resident in HBM: training-mode forward of the real_only Classifier (Kt=75, 3->32->64->64),
+CrossEntropyLoss, backward through every HIP kernel, [one RCCL all-reduce of the flat gradient
+bucket when world > 1], Adam.step().  Workload = BASELINE configs[1]'s tensor
+(N=4096 x 3 x 240 x 16, fp32) per GPU; weak scaling (per-GPU batch fixed).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--no-cpu] [--no-kernels]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the temporal-conv MFMA
+kernels), timed live with HIP events on the launch stream; `cpu_baseline` is the CPU oracle
+(a from-scratch port of the reference's PyTorch path) on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+
+
+def make_model(device, kt=75):
+    from step_amd.net.classifier import Classifier
+    torch.manual_seed(0)
+    m = Classifier(3, 4, {"strategy": "spatial"}, temporal_kernel_size=kt)
+    # weights_init of the reference harness (processor.py:117-129)
+    with torch.no_grad():
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Conv2d):
+                mod.weight.normal_(0.0, 0.02)
+                mod.bias.zero_()
+            elif isinstance(mod, torch.nn.modules.batchnorm._BatchNorm):
+                mod.weight.normal_(1.0, 0.02)
+                mod.bias.zero_()
+    return m.to(device)
+
+
+def synth(n, t, seed, device):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, 3, t, 16, 1, generator=g) * 0.5
+    y = torch.randint(0, 4, (n,), generator=g)
+    return x.to(device), y.to(device)
+
+
+def tcn_flops(n, c, t_out, kt=75):
+    return 2.0 * c * c * kt * t_out * 16 * n
+
+
+def time_kernels(n, t, device, reps=3):
+    """HIP-event timing of each temporal-conv kernel of the step (fwd, dgrad, wgrad x 3 blocks),
+    launched alone on the current stream."""
+    from step_amd import ops
+    out = []
+    blocks = [(32, 1, t), (64, 2, t), (64, 1, (t - 1) // 2 + 1)]
+    g = torch.Generator().manual_seed(7)
+    for bi, (c, s, tin) in enumerate(blocks):
+        tout = (tin - 1) // s + 1
+        y = torch.randn(n, c, tin, 16, generator=g).to(device)
+        du = torch.randn(n, c, tout, 16, generator=g).to(device)
+        w = (torch.randn(c, c, 75, 1, generator=g) * 0.02).to(device)
+        b = torch.zeros(c, device=device)
+        sc = torch.ones(c, device=device)
+        sh = torch.zeros(c, device=device)
+        wp = ops.tcn_pack(w, c, c, 75, s, 0)
+        wpd = ops.tcn_pack(w, c, c, 75, s, 2)
+        calls = {
+            "tcn_fwd": lambda: ops.tcn_conv(y, sc, sh, True, wp, b, None, None, None, None, None, False,
+                                            n, c, c, tin, tout, 75, s, 0),
+            "tcn_dgrad": lambda: ops.tcn_conv(du, None, None, False, wpd, None, None, None, None, None,
+                                              None, False, n, c, c, tin, tout, 75, s, 2),
+            "tcn_wgrad": lambda: ops.tcn_wgrad(du, y, sc, sh, True, n, c, c, tin, tout, 75, s, False,
+                                               w.shape),
+        }
+        for name, fn in calls.items():
+            fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / reps
+            fl = tcn_flops(n, c, tout)
+            out.append({"kernel": "%s_b%d" % (name, bi), "C": c, "stride": s, "ms": round(ms, 3),
+                        "tflops": round(fl / ms / 1e9, 2),
+                        "frac": round(fl / ms / 1e9 / PEAK_FP32_MFMA_TFLOPS, 4)})
+        del y, du
+    return out
+
+
+def cpu_baseline(t, kt=75, n=256):
+    """The oracle (port of the reference's PyTorch CPU path) on a bounded sample: fwd+bwd of n
+    sequences at the bench's T, on the box's host cores."""
+    from oracle import stgcn
+    threads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
+    torch.set_num_threads(threads)
+    m = make_model("cpu", kt)
+    P = {k: v.clone() for k, v in m.state_dict().items()}
+    x, y = synth(n, t, 99, "cpu")
+    stgcn.classifier_loss_and_grads(P, x[:2], y[:2], "real_only")          # warm-up
+    t0 = time.perf_counter()
+    stgcn.classifier_loss_and_grads(P, x, y, "real_only")
+    dt = time.perf_counter() - t0
+    return {"value": round(n / dt, 3), "unit": "sequences/s", "cores": threads, "kind": "port",
+            "sample": "oracle fwd+bwd (CrossEntropy, no optimizer), N=%d x 3 x %d x 16 fp32, %.1f s"
+                      % (n, t, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=4096, help="per-GPU batch (sequences)")
+    ap.add_argument("--frames", type=int, default=240)
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-kernels", action="store_true")
+    args = ap.parse_args()
+
+    from step_amd import parallel
+    import torch.distributed as dist
+    rank, local, world = parallel.init_from_env()
+    if world != args.gpus and rank == 0:
+        print("warning: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+
+    model = make_model(device).train()
+    parallel.broadcast_parameters(model)
+    opt = torch.optim.Adam(model.parameters(), lr=0.1, weight_decay=1e-4)
+    bucket = parallel.GradBucket(model.parameters())
+    x, y = synth(args.batch, args.frames, 1234 + rank, device)
+
+    def step():
+        out, _ = model(x)
+        loss = F.cross_entropy(out, y)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        bucket.all_reduce_mean()
+        opt.step()
+        return loss
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tdt = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tdt, op=dist.ReduceOp.MAX)
+        dt = float(tdt)
+    seq_per_s = args.batch * world * args.steps / dt
+
+    # forward-only (eval, fused epilogues) rate of the same tensor, for reference
+    model.eval()
+    with torch.no_grad():
+        model(x)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            model(x)
+        torch.cuda.synchronize()
+        infer = args.batch * 3 / (time.perf_counter() - t1)
+
+    kernels, roof = None, None
+    if rank == 0 and not args.no_kernels:
+        del x
+        torch.cuda.empty_cache()
+        kernels = time_kernels(args.batch, args.frames, device)
+        dom = max(kernels, key=lambda k: k["ms"])
+        roof = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"],
+                "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": dom["frac"], "traffic": None}
+    cpu = None
+    if rank == 0 and not args.no_cpu:
+        cpu = cpu_baseline(args.frames)
+
+    if rank == 0:
+        line = {
+            "metric": "ST-GCN fwd+bwd sequences/sec", "value": round(seq_per_s, 1), "unit": "sequences/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1] tensor: real_only ST-GCN classifier (Kt=75, 3->32->64->64), "
+                                   "N=%d x 3 x %d x 16 per GPU, fp32; step = train-mode fwd + CrossEntropy + bwd "
+                                   "+ grad all-reduce + Adam" % (args.batch, args.frames),
+                       "global_batch": args.batch * world, "frames": args.frames,
+                       "parallelism": "dp%d" % world},
+            "inference_sequences_per_s_per_gpu": round(infer, 1),
+            "step_tflops_per_gpu": round(9.30e9 * args.batch * args.steps / dt / 1e12, 2),
+            "roofline": roof, "kernels": kernels, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
