@@ -94,7 +94,7 @@ int step_masked_add(const float* dy, const float* mask_src, float* dx, int accum
  * residual branch `Conv2d(Ci,Co,1,stride=(s,1))` classifier.py:175-179 sharing the x tile.
  *   x (N,Ci,T,16)  w (K*Co,Ci) | (Ci,K*Co) if w_transposed   b (K*Co)
  *   A_eff (K,16,16) = A * edge_importance (classifier.py:78); a_nnz_max bounds the
- *   non-zeros per (k, column w) of A_eff (16 = dense, always valid).
+ *   non-zeros of every (k, column) AND every (k, row) of A_eff (16 = dense, always valid).
  *   y (N,Co,T,16) raw graph-conv output (pre tcn[0]);  res_out (N,Co,To,16) raw, To=(T-1)/s+1.
  */
 int step_gcn_fwd(const float* x, const float* in_scale, const float* in_shift,

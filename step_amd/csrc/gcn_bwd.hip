@@ -39,6 +39,28 @@ struct GbParams {
 
 __device__ __forceinline__ int rowmap(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
+// row-v non-zeros of A_k (the transposed pattern) into LDS: rellv/relli[(k*EMAX+e)*16 + v] = (A[k,v,w], w)
+template <int EMAX>
+__device__ __forceinline__ void build_row_ell(const float* A, int K, float* rellv, int* relli, int tid) {
+    if (tid >= 64 && tid < 112) {
+        const int k = (tid - 64) >> 4, v = tid & 15;
+        int cnt = 0;
+        if (k < K)
+            for (int w = 0; w < 16; ++w) {
+                const float a = A[(k * 16 + v) * 16 + w];
+                if (a != 0.f && cnt < EMAX) {
+                    rellv[(k * EMAX + cnt) * 16 + v] = a;
+                    relli[(k * EMAX + cnt) * 16 + v] = w;
+                    ++cnt;
+                }
+            }
+        for (; cnt < EMAX; ++cnt) {
+            rellv[(k * EMAX + cnt) * 16 + v] = 0.f;
+            relli[(k * EMAX + cnt) * 16 + v] = 0;
+        }
+    }
+}
+
 // column-w non-zeros of A_k into LDS (ELL form), every k < 3 (zero for k >= K)
 template <int EMAX>
 __device__ __forceinline__ void build_ell(const float* A, int K, float* ellv, int* elli, int tid) {
@@ -74,24 +96,33 @@ __device__ __forceinline__ float4 load_x4(const GbParams& p, int n, int ci, int 
 }
 
 // ------------------------------------------------------------------ kernel 1: dx, dA
+// dz stays in the MFMA accumulators (column = (t, w) on the lane, row = (k, ci) in the
+// register).  dx needs SUM_w A[k,v,w] dz[.., w]: the 16 lanes of one frame exchange dz with
+// ds_bpermute along the row lists of A, so dx is produced in the same register layout and
+// stored straight to HBM (128-byte rows); nothing is scattered through LDS.
 template <int CIP, int COPAD, int EMAX>
 __global__ __launch_bounds__(256) void gcn_bwd_data_kernel(GbParams p) {
     constexpr int KQ = 3 * CIP;
     constexpr int MQT = (KQ + 31) / 32;
     constexpr int KQP = MQT * 32;
     constexpr int MCI = (CIP + 31) / 32;            // ci tiles of the residual product
+    constexpr int NDX = CIP >= 32 ? (CIP / 32) * 16 : 4;   // dx registers per lane
+    constexpr bool REG = EMAX <= 4;                  // adjacency lists live in registers
+    constexpr int EL = REG ? EMAX : 1;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Wq = smem;                                // [COPAD][KQP]   W[(k,c),ci] as [c][k*CIP+ci]
-    float* dys = Wq + COPAD * KQP;                   // [COPAD][P]
-    float* xs = dys + COPAD * P;                     // [CIP][P]
-    float* dxs = xs + CIP * P;                       // [CIP][P]
-    float* ellv = dxs + CIP * P;                     // [3][EMAX][16]
+    float* dys = Wq + COPAD * KQP;                   // [COPAD][P]     dy tile, later the dres tile
+    float* xs = dys + COPAD * P;                     // [CIP][P]       x tile, later Wr^T dres
+    float* ellv = xs + CIP * P;                      // [3][EMAX][16]  column lists
     int* elli = reinterpret_cast<int*>(ellv + 3 * EMAX * 16);
+    float* rellv = reinterpret_cast<float*>(elli + 3 * EMAX * 16);   // row lists
+    int* relli = reinterpret_cast<int*>(rellv + 3 * EMAX * 16);
     float* red = dys;                                // [4][3*EMAX*16], aliases dys after the loop
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5, w16 = lane & 15;
     const int trow = 2 * wave + (l31 >> 4);
+    const int lbase = lane & ~15;
 
     for (int e = tid; e < COPAD * KQP; e += 256) {
         const int q = e % KQP, c = e / KQP;
@@ -103,17 +134,20 @@ __global__ __launch_bounds__(256) void gcn_bwd_data_kernel(GbParams p) {
         Wq[e] = v;
     }
     build_ell<EMAX>(p.A, p.K, ellv, elli, tid);
+    build_row_ell<EMAX>(p.A, p.K, rellv, relli, tid);
     __syncthreads();
 
-    float av[3][EMAX <= 4 ? EMAX : 1];
-    int ai[3][EMAX <= 4 ? EMAX : 1];
-    if (EMAX <= 4) {
+    float av[3][EL], rv[3][EL];
+    int ai[3][EL], ri[3][EL];
+    if (REG) {
 #pragma unroll
         for (int k = 0; k < 3; ++k)
 #pragma unroll
-            for (int e = 0; e < (EMAX <= 4 ? EMAX : 1); ++e) {
+            for (int e = 0; e < EL; ++e) {
                 av[k][e] = ellv[(k * EMAX + e) * 16 + w16];
                 ai[k][e] = elli[(k * EMAX + e) * 16 + w16];
+                rv[k][e] = rellv[(k * EMAX + e) * 16 + w16];
+                ri[k][e] = relli[(k * EMAX + e) * 16 + w16] + lbase;
             }
     }
     float dAacc[3][EMAX];
@@ -139,7 +173,6 @@ __global__ __launch_bounds__(256) void gcn_bwd_data_kernel(GbParams p) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (ci < p.Ci && t0 + row < p.T) v = load_x4(p, n, ci, t0 + row, vq);
             *reinterpret_cast<float4*>(xs + ci * P + row * 16 + vq * 4) = v;
-            *reinterpret_cast<float4*>(dxs + ci * P + row * 16 + vq * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         __syncthreads();
 
@@ -159,7 +192,9 @@ __global__ __launch_bounds__(256) void gcn_bwd_data_kernel(GbParams p) {
                     acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[s * 2 * KQP + m * 32], bv, acc[m], 0, 0, 0);
             }
         }
-        // scatter through A^T into dx, and x (x) dz into dA
+        float dxr[NDX];
+#pragma unroll
+        for (int i = 0; i < NDX; ++i) dxr[i] = 0.f;
 #pragma unroll
         for (int m = 0; m < MQT; ++m)
 #pragma unroll
@@ -167,25 +202,33 @@ __global__ __launch_bounds__(256) void gcn_bwd_data_kernel(GbParams p) {
                 const int rr = (r & 3) + 8 * (r >> 2);               // row without the lane half
                 const int kq = (m * 32 + rr) / CIP;                   // static for CIP in {8,32,64}
                 if (kq < 3) {
-                    const int q = m * 32 + rr + 4 * half;
-                    const int ci = q - kq * CIP;
+                    const int ci = m * 32 + rr + 4 * half - kq * CIP;
+                    const int slot = CIP >= 32 ? ((m * 32) % CIP) / 32 * 16 + r : (r & 3);
                     const float dz = acc[m][r];
-                    const int base = ci * P + trow * 16;
+                    const float* xrow = xs + ci * P + trow * 16;
+                    float dxa = 0.f;
 #pragma unroll
                     for (int e = 0; e < EMAX; ++e) {
-                        float a;
-                        int v;
-                        if (EMAX <= 4) { a = av[kq][e]; v = ai[kq][e]; }
-                        else { a = ellv[(kq * EMAX + e) * 16 + w16]; v = elli[(kq * EMAX + e) * 16 + w16]; }
-                        atomicAdd(&dxs[base + v], a * dz);
-                        dAacc[kq][e] = fmaf(xs[base + v], dz, dAacc[kq][e]);
+                        float a, rw;
+                        int v, src;
+                        if (REG) { a = av[kq][e]; v = ai[kq][e]; rw = rv[kq][e]; src = ri[kq][e]; }
+                        else {
+                            a = ellv[(kq * EMAX + e) * 16 + w16]; v = elli[(kq * EMAX + e) * 16 + w16];
+                            rw = rellv[(kq * EMAX + e) * 16 + w16];
+                            src = relli[(kq * EMAX + e) * 16 + w16] + lbase;
+                        }
+                        (void)a;
+                        dxa = fmaf(rw, __shfl(dz, src, 64), dxa);
+                        dAacc[kq][e] = fmaf(xrow[v], dz, dAacc[kq][e]);
                     }
+                    dxr[slot] += dxa;
                 }
             }
 
-        // residual branch: dx[ci, s*t', w] += SUM_c Wr[c,ci] dres[c, t', w]
+        // residual branch: dx[ci, s*t', w] += SUM_c Wr[c,ci] dres[c, t', w]   (through LDS: for
+        // stride 2 the output columns of this product belong to other waves' frames)
         if (p.dres) {
-            __syncthreads();                                          // dys no longer needed
+            __syncthreads();                                          // dys and xs are free now
             const int npos = p.stride == 1 ? 128 : 64;
             const int tr0 = t0 / p.stride;
             for (int f = tid; f < COPAD * (npos / 4); f += 256) {
@@ -218,23 +261,29 @@ __global__ __launch_bounds__(256) void gcn_bwd_data_kernel(GbParams p) {
                         ar[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, ar[m], 0, 0, 0);
                     }
                 }
-                const int lrow = p.stride * trow;                     // local input frame
 #pragma unroll
                 for (int m = 0; m < MCI; ++m)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int ci = m * 32 + rowmap(r, half);
-                        if (ci < CIP) atomicAdd(&dxs[ci * P + lrow * 16 + w16], ar[m][r]);
+                        if (ci < CIP) xs[ci * P + wave * 32 + l31] = ar[m][r];
                     }
             }
+            __syncthreads();
+            const bool mine = p.stride == 1 || (trow & 1) == 0;
+            const int col = p.stride == 1 ? trow * 16 + w16 : (trow >> 1) * 16 + w16;
+#pragma unroll
+            for (int i = 0; i < NDX; ++i) {
+                const int ci = CIP >= 32 ? (i / 16) * 32 + rowmap(i & 15, half) : i + 4 * half;
+                if (mine) dxr[i] += xs[ci * P + col];
+            }
         }
-        __syncthreads();
-        if (p.dx) {
-            for (int f = tid; f < CIP * 32; f += 256) {
-                const int ci = f >> 5, row = (f & 31) >> 2, vq = f & 3;
-                if (ci < p.Ci && t0 + row < p.T)
-                    *reinterpret_cast<float4*>(p.dx + (((size_t)n * p.Ci + ci) * p.T + t0 + row) * 16 + vq * 4) =
-                        *reinterpret_cast<const float4*>(dxs + ci * P + row * 16 + vq * 4);
+        if (p.dx && t0 + trow < p.T) {
+#pragma unroll
+            for (int i = 0; i < NDX; ++i) {
+                const int ci = CIP >= 32 ? (i / 16) * 32 + rowmap(i & 15, half) : i + 4 * half;
+                if (ci < p.Ci)
+                    p.dx[(((size_t)n * p.Ci + ci) * p.T + t0 + trow) * 16 + w16] = dxr[i];
             }
         }
     }
@@ -486,6 +535,23 @@ __global__ void gcn_bwd_finalize_kernel(FinParams f) {
     }
 }
 
+// dst[c] = SUM_r src[r][c], rows in order (reproducible); 4 independent chains per thread
+__global__ void sum_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int nrows,
+                                int ncols) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncols) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int r = 0;
+    for (; r + 3 < nrows; r += 4) {
+        s0 += src[(size_t)r * ncols + c];
+        s1 += src[(size_t)(r + 1) * ncols + c];
+        s2 += src[(size_t)(r + 2) * ncols + c];
+        s3 += src[(size_t)(r + 3) * ncols + c];
+    }
+    for (; r < nrows; ++r) s0 += src[(size_t)r * ncols + c];
+    dst[c] = (s0 + s1) + (s2 + s3);
+}
+
 struct GbGeom {
     int cip, copad, emax, cir, nblk1, nblk2;
     size_t lds1, lds2, part1, part2;
@@ -498,8 +564,8 @@ bool gb_geom(int N, int Ci, int Co, int T, int nnz, GbGeom* g) {
     g->emax = nnz <= 4 ? 4 : 16;
     g->cir = g->cip <= 32 ? 32 : 64;
     const int kqp = ((3 * g->cip + 31) / 32) * 32;
-    g->lds1 = ((size_t)g->copad * kqp + (size_t)g->copad * P + 2 * (size_t)g->cip * P +
-               2 * 3 * (size_t)g->emax * 16) * 4;
+    g->lds1 = ((size_t)g->copad * kqp + (size_t)g->copad * P + (size_t)g->cip * P +
+               4 * 3 * (size_t)g->emax * 16) * 4;
     g->lds2 = ((size_t)g->copad * PS + 2 * (size_t)g->cir * PS + 2 * 3 * (size_t)g->emax * 16) * 4;
     const long long ntiles = (long long)N * ((T + TT - 1) / TT);
     auto blocks = [&](size_t lds) {
@@ -558,7 +624,7 @@ extern "C" size_t step_gcn_bwd_ws_bytes(int N, int Ci, int Co, int K, int T) {
     for (int nnz = 4; nnz <= 16; nnz += 12) {             // both kernel variants
         GbGeom g;
         if (!gb_geom(N, Ci, Co, T, nnz, &g)) continue;
-        const size_t need = ((size_t)g.nblk1 * g.part1 + (size_t)g.nblk2 * g.part2) * 4;
+        const size_t need = ((size_t)(g.nblk1 + 1) * g.part1 + (size_t)(g.nblk2 + 1) * g.part2) * 4;
         best = need > best ? need : best;
     }
     return best;
@@ -578,7 +644,7 @@ extern "C" int step_gcn_bwd(const float* dy, const float* dres, const float* x, 
     GbGeom g;
     STEP_REQUIRE(gb_geom(N, Ci, Co, T, a_nnz_max, &g), "step_gcn_bwd: unsupported N=%d Ci=%d Co=%d T=%d", N,
                  Ci, Co, T);
-    const size_t need = ((size_t)g.nblk1 * g.part1 + (size_t)g.nblk2 * g.part2) * 4;
+    const size_t need = ((size_t)(g.nblk1 + 1) * g.part1 + (size_t)(g.nblk2 + 1) * g.part2) * 4;
     if (ws_bytes < need) {
         step::set_error("step_gcn_bwd: workspace %zu < %zu bytes", ws_bytes, need);
         return STEP_ERR_WORKSPACE;
@@ -595,10 +661,16 @@ extern "C" int step_gcn_bwd(const float* dy, const float* dres, const float* x, 
     hipStream_t st = (hipStream_t)stream;
     int rc = g.emax == 4 ? dispatch_gb<4>(p, g, st) : dispatch_gb<16>(p, g, st);
     if (rc) return rc;
+    float* tot1 = p.part2 + (size_t)g.nblk2 * g.part2;
+    float* tot2 = tot1 + g.part1;
+    hipLaunchKernelGGL(sum_rows_kernel, dim3(step::ceil_div((int)g.part1, 128)), dim3(128), 0, st, p.part1,
+                       tot1, g.nblk1, (int)g.part1);
+    hipLaunchKernelGGL(sum_rows_kernel, dim3(step::ceil_div((int)g.part2, 128)), dim3(128), 0, st, p.part2,
+                       tot2, g.nblk2, (int)g.part2);
     FinParams f{};
-    f.part1 = p.part1; f.part2 = p.part2; f.A = A_eff; f.b = b;
+    f.part1 = tot1; f.part2 = tot2; f.A = A_eff; f.b = b;
     f.dw = dw; f.db = db; f.dA = dA; f.dres_w = dres_w; f.dres_b = dres_b;
-    f.nblk1 = g.nblk1; f.nblk2 = g.nblk2; f.emax = g.emax; f.copad = g.copad; f.cir = g.cir;
+    f.nblk1 = 1; f.nblk2 = 1; f.emax = g.emax; f.copad = g.copad; f.cir = g.cir;
     f.Ci = Ci; f.Co = Co; f.K = K; f.w_transposed = w_transposed; f.res_transposed = res_transposed;
     f.have_res = dres != nullptr;
     const int total = K * Co * Ci + Co * Ci + Co + K * Co + K * 16;

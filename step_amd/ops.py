@@ -22,9 +22,10 @@ def _f32(t):
 
 
 def a_nnz_max(A):
-    """Largest number of non-zeros in a (k, column w) of the fixed adjacency A (host side,
-    once per model).  A * edge_importance keeps A's zeros, so this bounds A_eff too."""
-    return int((A != 0).sum(dim=1).max().item())
+    """Largest number of non-zeros in any (k, column) or (k, row) of the fixed adjacency A (host
+    side, once per model).  A * edge_importance keeps A's zeros, so this bounds A_eff too."""
+    nz = A != 0
+    return int(max(nz.sum(dim=1).max().item(), nz.sum(dim=2).max().item()))
 
 
 # ------------------------------------------------------------------------ BatchNorm

@@ -124,7 +124,7 @@ def test_gcn_fwd_bwd(Ci, Co, T, N, transposed, dense):
     y.backward(gy)
     d = dev()
     gl = [t.clone().to(d).requires_grad_(True) for t in (x, A, w, b)]
-    nnz = 16 if dense else 3
+    nnz = 16 if dense else 4
     yg = GcnFn.apply(gl[0], gl[1], gl[2], gl[3], transposed, nnz)
     assert_close(yg, y, TOL, "gcn y")
     yg.backward(gy.to(d))
