@@ -1,0 +1,158 @@
+"""CPU (no GPU needed): the C-ABI library loads and exports every symbol include/step_hip.h
+declares; the host-side module contract (constructors, state_dict keys, checkpoint loading,
+weights_init by class name); loud failure without a GPU; the data-parallel path on gloo."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from tests.util import load_npz, ckpt
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    txt = open(os.path.join(ROOT, "include", "step_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(step_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    from step_amd import _lib
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    syms = header_symbols()
+    assert len(syms) >= 25
+    for s in syms:
+        assert hasattr(lib, s), "libstep_hip.so lacks %s" % s
+        assert s in _lib.SIGNATURES, "ctypes binding lacks %s" % s
+    assert set(_lib.SIGNATURES) == set(syms)
+    l = _lib.load()
+    assert l.step_abi_version() == 1
+    # size helpers are pure host code: callable without a GPU
+    assert l.step_bn_ws_bytes(48) > 0
+    assert l.step_tcn_packed_elems(64, 64, 75, 1, 0) == 64 * 76 * 64
+    assert l.step_tcn_packed_elems(64, 64, 75, 2, 2) == 64 * 38 * 128
+    assert l.step_tcn_packed_elems(64, 64, 8, 1, 0) == 0          # even Kt is rejected
+    assert l.step_tcn_wgrad_ws_bytes(512, 64, 64, 240, 120, 75) > 0
+    assert l.step_gcn_bwd_ws_bytes(512, 64, 64, 3, 240) > 0
+
+
+def test_shape_errors_are_reported_before_launch():
+    from step_amd import _lib
+    l = _lib.load()
+    rc = l.step_tcn_conv(None, None, None, 0, None, None, None, None, None, None, None, 0, None,
+                         1, 3, 3, 10, 10, 75, 1, 0, None)
+    assert rc == -1 and b"null pointer" in l.step_last_error()
+    rc = l.step_gcn_fwd(1, None, None, 1, None, 0, 1, 4, 1, None, None, 0, None, 2, 3, 128, 3, 10, 1, None)
+    assert rc == -1 and b"Co=128" in l.step_last_error()
+
+
+def test_models_keep_reference_state_dict_contract():
+    from step_amd.net import classifier, classifier_real_and_synth, classifier_hybrid, CVAE_stgcn
+    g = {"strategy": "spatial"}
+    z = load_npz("ckpt_classifier_real_only_epoch395")
+    m = classifier.Classifier(3, 4, g)
+    sd = m.state_dict()
+    assert list(sd) == list(z.files)
+    assert all(tuple(sd[k].shape) == z[k].shape for k in z.files)
+    m.load_state_dict(ckpt("ckpt_classifier_real_only_epoch395"))
+    np.testing.assert_array_equal(m.A.numpy(), z["A"])
+    assert sum(p.numel() for p in m.parameters()) == 716292
+    zc = load_npz("ckpt_cvae_epoch105")
+    c = CVAE_stgcn.CVAE(3, 75, 16, 32, 4, g)
+    assert list(c.state_dict()) == list(zc.files)
+    c.load_state_dict(ckpt("ckpt_cvae_epoch105"))
+    assert sum(p.numel() for p in c.parameters()) == 876484
+    tr = load_npz("train_steps")
+    for variant, mod in (("real_and_synth", classifier_real_and_synth.Classifier(3, 4, g, temporal_kernel_size=9)),
+                         ("hybrid", classifier_hybrid.Classifier(3, 29, 4, g, temporal_kernel_size=9))):
+        keys = [k[len(variant) + 7:] for k in tr.files if k.startswith(variant + "_k9.P0.")]
+        assert list(mod.state_dict()) == keys, variant
+    # GuidedBackprop of the reference reaches these attributes (processor.py:35,62-66)
+    assert isinstance(m.st_gcn_networks[0].gcn.conv, torch.nn.Conv2d)
+    assert isinstance(m.st_gcn_networks[0].relu, torch.nn.ReLU)
+
+
+def test_weights_init_matches_by_class_name():
+    """processor.py:117-129 dispatches on the class NAME: Conv2d and BatchNorm* are re-initialised,
+    ConvTranspose2d is not."""
+    from step_amd.net import CVAE_stgcn
+    names = {type(mod).__name__ for mod in CVAE_stgcn.CVAE(3, 75, 16, 32, 4, {"strategy": "spatial"}).modules()}
+    assert {"Conv2d", "ConvTranspose2d", "BatchNorm1d", "BatchNorm2d"} <= names
+    for n in names:
+        if n.startswith("ConvT"):
+            assert n.find("Conv2d") == -1
+
+
+def test_cpu_input_fails_loudly():
+    from step_amd.net import classifier
+    from step_amd._lib import StepHipError
+    m = classifier.Classifier(3, 4, {"strategy": "spatial"})
+    with pytest.raises(StepHipError):
+        m(torch.zeros(2, 3, 20, 16, 1))
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "step_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                txt = open(os.path.join(dp, f)).read()
+                assert "oracle" not in txt.replace("# oracle", ""), os.path.join(dp, f)
+
+
+def test_shard_batch_partitions():
+    from step_amd.parallel import shard_batch
+    for n, w in ((4096, 8), (100000, 8), (7, 3), (5, 8)):
+        cuts = [shard_batch(n, r, w) for r in range(w)]
+        assert cuts[0][0] == 0 and cuts[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(cuts, cuts[1:]))
+        sizes = [b - a for a, b in cuts]
+        assert max(sizes) - min(sizes) <= 1
+
+
+_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, '__ROOT__')
+from step_amd import parallel
+rank, local, world = parallel.init_from_env(backend="gloo")
+torch.manual_seed(0)
+lin = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Linear(5, 3))
+with torch.no_grad():
+    for p in lin.parameters():
+        p.add_(rank)                      # ranks start different ...
+parallel.broadcast_parameters(lin)        # ... and are made equal to rank 0
+g = torch.Generator().manual_seed(1)
+X = torch.randn(8, 6, generator=g); Y = torch.randint(0, 3, (8,), generator=g)
+a, b = parallel.shard_batch(8, rank, world)
+loss = torch.nn.functional.cross_entropy(lin(X[a:b]), Y[a:b])
+loss.backward()
+bucket = parallel.GradBucket(lin.parameters())
+bucket.all_reduce_mean()
+# single-process reference on the full batch (equal shard sizes -> mean of shard means)
+ref = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Linear(5, 3))
+torch.manual_seed(0)
+ref = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Linear(5, 3))
+torch.nn.functional.cross_entropy(ref(X), Y).backward()
+for p, q in zip(lin.parameters(), ref.parameters()):
+    assert torch.allclose(p.grad, q.grad, atol=1e-6), (rank, (p.grad - q.grad).abs().max())
+assert bucket.numel == sum(p.numel() for p in ref.parameters())
+dist.barrier(); dist.destroy_process_group()
+sys.stdout.write("rank%d-ok\n" % rank); sys.stdout.flush()
+"""
+
+
+def test_gradient_allreduce_two_ranks_gloo(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER.replace('__ROOT__', ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29517", OMP_NUM_THREADS="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29517", str(script)],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "rank0-ok" in out.stdout and "rank1-ok" in out.stdout
