@@ -30,42 +30,64 @@ struct WgParams {
     float* slab;        // [nsplit][Co][Q]
     float* dbslab;      // [nsplit][Co]
     int in_relu;
-    int N, Ci, Co, Tin, Tout, Kt, stride, pad;
-    int Q, nqb, nsplit, RW, RS, VS, NCH;
+    int N, Ci, Co, Tin, Tout, pad;
+    int Q, nqb, nsplit;
 };
 
-template <int MW, int NQ>
+// compile-time geometry of one (MW, NQ, Kt, stride) variant
+template <int MW, int NQ, int KT, int STRIDE>
+struct WgCfg {
+    static constexpr int QW = 4 / MW;                         // column groups (waves) per block
+    static constexpr int QB = QW * NQ * 32;                   // q's per block
+    static constexpr int RW = STRIDE * (WG_TT - 1) + KT;      // staged input rows per chunk
+    static constexpr int RS = RW + ((KT - RW) % 32 + 32) % 32;   // >= RW and == KT (mod 32)
+    static constexpr int NCH0 = (QB + KT - 1) / KT + 1;
+    static constexpr int NCH = NCH0 < 32 * MW ? NCH0 : 32 * MW;  // never more than Ci channels
+    static constexpr int VS = NCH * RS + 1;
+    static constexpr int A_ITEMS = NCH * RW * 4;              // float4 items of the strip
+    static constexpr int D_ITEMS = 32 * MW * 32;
+    static constexpr int LDS_FLOATS = 32 * MW * WG_DS + 16 * VS;
+};
+
+// Software-pipelined variant (DB = true, used when two LDS images fit): while the 320 MFMAs of
+// chunk i run from LDS image i&1, the same waves fetch chunk i+1 in 7 small batches (global ->
+// registers at frame step tl, registers -> the other LDS image at step tl+1), so the staging
+// latency hides under the matrix pipe and one barrier per chunk remains.
+template <int MW, int NQ, int KT, int STRIDE, bool DB>
 __global__ __launch_bounds__(256) void tcn_wgrad_kernel(WgParams p) {
-    constexpr int QW = 4 / MW;                       // column groups (waves) per block
-    constexpr int QB = QW * NQ * 32;                 // q's per block
+    using C = WgCfg<MW, NQ, KT, STRIDE>;
+    constexpr int DN = C::D_ITEMS / 256;                         // dout float4 per thread (4 or 8)
+    constexpr int AN = (C::A_ITEMS + 255) / 256;                 // strip float4 per thread
+    constexpr int NSTEP = 7;                                     // batches per chunk
+    constexpr int DPS = (DN + NSTEP - 1) / NSTEP;                // items per batch
+    constexpr int APS = (AN + NSTEP - 1) / NSTEP;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* ds = smem;                                // [32*MW][WG_DS]
-    float* aT = smem + 32 * MW * WG_DS;              // [16][NCH][RS]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int mw = wave / QW;
-    const int qw = wave % QW;
+    const int mw = wave / C::QW;
+    const int qw = wave % C::QW;
     const int l31 = lane & 31;
     const int half = lane >> 5;
 
     const int qb = blockIdx.x % p.nqb;
     const int split = blockIdx.x / p.nqb;
-    const int q0 = qb * QB;
-    const int ch0 = q0 / p.Kt;                       // first channel this block touches
+    const int q0 = qb * C::QB;
+    const int ch0 = q0 / KT;                         // first channel this block touches
     const int n0 = (int)((long long)p.N * split / p.nsplit);
     const int n1 = (int)((long long)p.N * (split + 1) / p.nsplit);
 
-    // per-lane B base offsets (channel slot * RS + tap) of its column in each tile
-    int cbase[NQ];
+    // per-lane B offset (floats, inside the aT image) of its column in each tile
+    int bcol[NQ];
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
         int q = q0 + (qw * NQ + i) * 32 + l31;
         if (q >= p.Q) q = p.Q - 1;                   // clamp: result discarded at the store
-        const int ci = q / p.Kt;
-        cbase[i] = (ci - ch0) * p.RS + (q - ci * p.Kt) + half * p.VS;
+        const int ci = q / KT;
+        bcol[i] = 32 * MW * WG_DS + (ci - ch0) * C::RS + (q - ci * KT) + half * C::VS;
     }
+    const int aoff = (mw * 32 + l31) * WG_DS + half;
 
     f32x16 acc[NQ];
 #pragma unroll
@@ -75,36 +97,65 @@ __global__ __launch_bounds__(256) void tcn_wgrad_kernel(WgParams p) {
     float dbsum = 0.f;
 
     const int nchunks = (p.Tout + WG_TT - 1) / WG_TT;
-    for (int n = n0; n < n1; ++n) {
-        for (int ck = 0; ck < nchunks; ++ck) {
-            const int t0 = ck * WG_TT;
-            __syncthreads();
-            // dout tile: 32*MW channels x 128 positions
-            for (int f = tid; f < 32 * MW * 32; f += 256) {
-                const int co = f >> 5;
-                const int r4 = f & 31;                         // float4 index within 128 positions
+    const int total = (n1 - n0) * nchunks;
+
+    float4 dv[DPS], av[APS];
+    // issue the global loads of batch `step` of chunk (n, t0)
+    auto batch_load = [&](int step, int n, int t0) {
+        const float* dbase = p.dout + (size_t)n * p.Co * p.Tout * 16;          // wave-uniform
+        const float* abase = p.in + ((size_t)n * p.Ci + ch0) * p.Tin * 16;
+        const int row0 = STRIDE * t0 - p.pad;
+#pragma unroll
+        for (int k = 0; k < DPS; ++k) {
+            const int item = step * DPS + k;
+            dv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (item < DN) {
+                const int f = tid + item * 256;
+                const int co = f >> 5, r4 = f & 31;
                 const int t = t0 + (r4 >> 2);
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (co < p.Co && t < p.Tout)
-                    v = *reinterpret_cast<const float4*>(
-                        p.dout + (((size_t)n * p.Co + co) * p.Tout + t) * 16 + (r4 & 3) * 4);
-                float* d = ds + co * WG_DS + r4 * 4;
-                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+                    dv[k] = *reinterpret_cast<const float4*>(dbase + (co * p.Tout + t) * 16 + (r4 & 3) * 4);
             }
-            // activation strip, transposed: NCH channels x RW rows x 16 joints
-            const int row0 = p.stride * t0 - p.pad;
-            for (int f = tid; f < p.NCH * p.RW * 4; f += 256) {
-                const int cil = f / (p.RW * 4);
-                const int rem = f - cil * p.RW * 4;
+        }
+#pragma unroll
+        for (int k = 0; k < APS; ++k) {
+            const int item = step * APS + k;
+            av[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (item < AN) {
+                const int f = tid + item * 256;
+                const int cil = f / (C::RW * 4);
+                const int rem = f - cil * (C::RW * 4);
+                const int tin = row0 + (rem >> 2);
+                if (f < C::A_ITEMS && ch0 + cil < p.Ci && tin >= 0 && tin < p.Tin)
+                    av[k] = *reinterpret_cast<const float4*>(abase + (cil * p.Tin + tin) * 16 + (rem & 3) * 4);
+            }
+        }
+    };
+    // write batch `step` into the LDS image `img` (BN1 + ReLU applied to the strip here)
+    auto batch_store = [&](int step, float* img, int t0) {
+        const int row0 = STRIDE * t0 - p.pad;
+#pragma unroll
+        for (int k = 0; k < DPS; ++k) {
+            const int item = step * DPS + k;
+            if (item < DN) {
+                const int f = tid + item * 256;
+                float* d = img + (f >> 5) * WG_DS + (f & 31) * 4;
+                d[0] = dv[k].x; d[1] = dv[k].y; d[2] = dv[k].z; d[3] = dv[k].w;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < APS; ++k) {
+            const int item = step * APS + k;
+            const int f = tid + item * 256;
+            if (item < AN && f < C::A_ITEMS) {
+                const int cil = f / (C::RW * 4);
+                const int rem = f - cil * (C::RW * 4);
                 const int row = rem >> 2, vq = rem & 3;
-                const int ci = ch0 + cil;
                 const int tin = row0 + row;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (ci < p.Ci && tin >= 0 && tin < p.Tin) {
-                    v = *reinterpret_cast<const float4*>(
-                        p.in + (((size_t)n * p.Ci + ci) * p.Tin + tin) * 16 + vq * 4);
+                float4 v = av[k];
+                if (ch0 + cil < p.Ci && tin >= 0 && tin < p.Tin) {
                     if (p.in_scale) {
-                        const float sc = p.in_scale[ci], sh = p.in_shift[ci];
+                        const float sc = p.in_scale[ch0 + cil], sh = p.in_shift[ch0 + cil];
                         v.x = v.x * sc + sh; v.y = v.y * sc + sh; v.z = v.z * sc + sh; v.w = v.w * sc + sh;
                     }
                     if (p.in_relu) {
@@ -112,24 +163,63 @@ __global__ __launch_bounds__(256) void tcn_wgrad_kernel(WgParams p) {
                         v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
                     }
                 }
-                float* d = aT + (vq * 4) * p.VS + cil * p.RS + row;
-                d[0] = v.x; d[p.VS] = v.y; d[2 * p.VS] = v.z; d[3 * p.VS] = v.w;
+                float* d = img + 32 * MW * WG_DS + (vq * 4) * C::VS + cil * C::RS + row;
+                d[0] = v.x; d[C::VS] = v.y; d[2 * C::VS] = v.z; d[3 * C::VS] = v.w;
+            }
+        }
+    };
+    auto mfma_frame = [&](const float* img, int tl) {
+#pragma unroll
+        for (int v2 = 0; v2 < 8; ++v2) {
+            const float a = img[aoff + tl * 16 + v2 * 2];
+            dbsum += a;
+#pragma unroll
+            for (int i = 0; i < NQ; ++i)
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                    a, img[bcol[i] + STRIDE * tl + 2 * v2 * C::VS], acc[i], 0, 0, 0);
+        }
+    };
+
+    if (DB) {
+        if (total > 0) {
+#pragma unroll 1
+            for (int s = 0; s < NSTEP; ++s) {         // prologue: chunk 0, not overlapped
+                batch_load(s, n0, 0);
+                batch_store(s, smem, 0);
+            }
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int it = 0; it < total; ++it) {
+            const float* cur = smem + (it & 1) * C::LDS_FLOATS;
+            float* nxt = smem + ((it + 1) & 1) * C::LDS_FLOATS;
+            const bool more = it + 1 < total;
+            const int nn = n0 + (it + 1) / nchunks;
+            const int nt0 = ((it + 1) % nchunks) * WG_TT;
+#pragma unroll
+            for (int tl = 0; tl < WG_TT; ++tl) {
+                if (more) {
+                    if (tl >= 1) batch_store(tl - 1, nxt, nt0);
+                    if (tl < NSTEP) batch_load(tl, nn, nt0);
+                }
+                mfma_frame(cur, tl);
             }
             __syncthreads();
-
-            const float* ap = ds + (mw * 32 + l31) * WG_DS + half;
-            for (int tl = 0; tl < WG_TT; ++tl) {
-                const float* bp = aT + p.stride * tl;
-#pragma unroll
-                for (int v2 = 0; v2 < 8; ++v2) {
-                    const float a = ap[tl * 16 + v2 * 2];
-                    dbsum += a;
-                    const float* bq = bp + (2 * v2) * p.VS;
-#pragma unroll
-                    for (int i = 0; i < NQ; ++i)
-                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq[cbase[i]], acc[i], 0, 0, 0);
-                }
+        }
+    } else {
+#pragma unroll 1
+        for (int it = 0; it < total; ++it) {
+            const int n = n0 + it / nchunks;
+            const int t0 = (it % nchunks) * WG_TT;
+            __syncthreads();
+#pragma unroll 1
+            for (int s = 0; s < NSTEP; ++s) {
+                batch_load(s, n, t0);
+                batch_store(s, smem, t0);
             }
+            __syncthreads();
+#pragma unroll 2
+            for (int tl = 0; tl < WG_TT; ++tl) mfma_frame(smem, tl);
         }
     }
 
@@ -180,34 +270,47 @@ __global__ void tcn_wgrad_reduce_kernel(const float* __restrict__ slab, const fl
 }
 
 struct WgGeom {
-    int mw, nq, qb, nqb, nsplit, RW, RS, VS, NCH;
+    int mw, qb, nqb, nsplit;
     size_t lds, ws;
 };
 
+template <int MW, int NQ, int KT, int STRIDE>
+void fill_geom(WgGeom* g) {
+    using C = WgCfg<MW, NQ, KT, STRIDE>;
+    g->qb = C::QB;
+    g->lds = (size_t)C::LDS_FLOATS * 4 * (KT == 75 ? 2 : 1);   // Kt=75: two LDS images (pipelined)
+}
+
 bool wg_geom(int N, int Ci, int Co, int Kt, int stride, WgGeom* g) {
-    if (Co > 64 || Co < 1 || Ci < 1 || Kt < 1 || N < 1) return false;
+    if (Co > 64 || Co < 1 || Ci < 1 || N < 1 || (stride != 1 && stride != 2)) return false;
     g->mw = Co > 32 ? 2 : 1;
-    g->nq = g->mw == 2 ? 5 : 4;
-    g->qb = (4 / g->mw) * g->nq * 32;
+    if (Ci > 32 * g->mw) return false;               // the temporal conv of the stack is square
+    const int key = Kt * 100 + stride * 10 + g->mw;
+    switch (key) {
+        case 7511: fill_geom<1, 4, 75, 1>(g); break;
+        case 7512: fill_geom<2, 5, 75, 1>(g); break;
+        case 7521: fill_geom<1, 4, 75, 2>(g); break;
+        case 7522: fill_geom<2, 5, 75, 2>(g); break;
+        case 911: fill_geom<1, 4, 9, 1>(g); break;
+        case 912: fill_geom<2, 5, 9, 1>(g); break;
+        case 921: fill_geom<1, 4, 9, 2>(g); break;
+        case 922: fill_geom<2, 5, 9, 2>(g); break;
+        default: return false;
+    }
     const int Q = Ci * Kt;
     g->nqb = step::ceil_div(Q, g->qb);
-    int ns = step::ceil_div(768, g->nqb);
+    // batch slices: nqb * nsplit blocks should fill whole rounds of the 256 CUs (one pipelined
+    // block per CU at Kt=75), or the last round runs mostly empty
+    int ns = (256 * 3) / g->nqb;
+    ns = ns < 1 ? 1 : ns;
     g->nsplit = ns < N ? ns : N;
-    g->RW = stride * (WG_TT - 1) + Kt;
-    int rs = g->RW;
-    while ((rs & 31) != (Kt & 31)) ++rs;               // channel stride == Kt (mod 32)
-    g->RS = rs;
-    g->NCH = (g->qb + Kt - 1) / Kt + 1;
-    if (g->NCH > Ci) g->NCH = Ci;                      // a block never touches more than Ci channels
-    g->VS = g->NCH * g->RS + 1;
-    g->lds = ((size_t)32 * g->mw * WG_DS + (size_t)16 * g->VS) * 4;
     g->ws = ((size_t)g->nsplit * Co * Q + (size_t)g->nsplit * Co) * 4;
     return g->lds <= 160 * 1024;
 }
 
-template <int MW, int NQ>
+template <int MW, int NQ, int KT, int STRIDE>
 int launch_wg(const WgParams& p, const WgGeom& g, hipStream_t st) {
-    auto kern = tcn_wgrad_kernel<MW, NQ>;
+    auto kern = tcn_wgrad_kernel<MW, NQ, KT, STRIDE, KT == 75>;
     if (g.lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds);
@@ -226,7 +329,7 @@ extern "C" size_t step_tcn_wgrad_ws_bytes(int N, int Ci, int Co, int Tin, int To
     WgGeom g;
     (void)Tin; (void)Tout;
     if (!wg_geom(N, Ci, Co, Kt, 1, &g)) return 0;
-    return g.ws;                                        // independent of the stride
+    return g.ws;                                        // nsplit does not depend on the stride
 }
 
 extern "C" int step_tcn_wgrad(const float* dout, const float* in, const float* in_scale,
@@ -250,12 +353,21 @@ extern "C" int step_tcn_wgrad(const float* dout, const float* in, const float* i
     p.dout = dout; p.in = in; p.in_scale = in_scale; p.in_shift = in_shift; p.in_relu = in_relu;
     p.slab = (float*)ws;
     p.dbslab = p.slab + (size_t)g.nsplit * Co * Ci * Kt;
-    p.N = N; p.Ci = Ci; p.Co = Co; p.Tin = Tin; p.Tout = Tout; p.Kt = Kt; p.stride = stride;
+    p.N = N; p.Ci = Ci; p.Co = Co; p.Tin = Tin; p.Tout = Tout;
     p.pad = (Kt - 1) / 2;
-    p.Q = Ci * Kt; p.nqb = g.nqb; p.nsplit = g.nsplit; p.RW = g.RW; p.RS = g.RS; p.VS = g.VS;
-    p.NCH = g.NCH;
+    p.Q = Ci * Kt; p.nqb = g.nqb; p.nsplit = g.nsplit;
     hipStream_t st = (hipStream_t)stream;
-    int rc = g.mw == 2 ? launch_wg<2, 5>(p, g, st) : launch_wg<1, 4>(p, g, st);
+    int rc = STEP_ERR_ARG;
+    switch (Kt * 100 + stride * 10 + g.mw) {
+        case 7511: rc = launch_wg<1, 4, 75, 1>(p, g, st); break;
+        case 7512: rc = launch_wg<2, 5, 75, 1>(p, g, st); break;
+        case 7521: rc = launch_wg<1, 4, 75, 2>(p, g, st); break;
+        case 7522: rc = launch_wg<2, 5, 75, 2>(p, g, st); break;
+        case 911: rc = launch_wg<1, 4, 9, 1>(p, g, st); break;
+        case 912: rc = launch_wg<2, 5, 9, 1>(p, g, st); break;
+        case 921: rc = launch_wg<1, 4, 9, 2>(p, g, st); break;
+        case 922: rc = launch_wg<2, 5, 9, 2>(p, g, st); break;
+    }
     if (rc) return rc;
     const int total = Co * Ci * Kt + Co;
     hipLaunchKernelGGL(tcn_wgrad_reduce_kernel, dim3(step::ceil_div(total, 256)), dim3(256), 0, st,
