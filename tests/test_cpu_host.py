@@ -35,8 +35,8 @@ def test_library_exports_every_declared_symbol():
     assert l.step_abi_version() == 1
     # size helpers are pure host code: callable without a GPU
     assert l.step_bn_ws_bytes(48) > 0
-    assert l.step_tcn_packed_elems(64, 64, 75, 1, 0) == 64 * 76 * 64
-    assert l.step_tcn_packed_elems(64, 64, 75, 2, 2) == 64 * 38 * 128
+    assert l.step_tcn_packed_elems(64, 64, 75, 1, 0) == 64 * 76 * 64 + 256
+    assert l.step_tcn_packed_elems(64, 64, 75, 2, 2) == 64 * 38 * 128 + 256
     assert l.step_tcn_packed_elems(64, 64, 8, 1, 0) == 0          # even Kt is rejected
     assert l.step_tcn_wgrad_ws_bytes(512, 64, 64, 240, 120, 75) > 0
     assert l.step_gcn_bwd_ws_bytes(512, 64, 64, 3, 240) > 0

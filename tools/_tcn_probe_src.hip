@@ -20,7 +20,7 @@
 // NT column tiles.  The K loop runs over input channels; per channel the block stages
 // the channel's input strip (BN1 + ReLU applied on the way in, padding rows zero) and
 // the channel's packed weights into double-buffered LDS, one barrier per channel.
-#include "common.h"
+#include "../step_amd/csrc/common.h"
 
 namespace {
 
@@ -51,10 +51,8 @@ struct TcnCfg {
     static constexpr int WCH = 2 * KS * MPAD;                 // packed weights of 1 channel
     static constexpr int NB = (STRIDE == 1) ? (NT + KS - 1) : (2 * (NT - 1) + KS);
     static constexpr int SF4 = (ROWS * 4 + NTHR - 1) / NTHR;  // float4 per thread
-    static constexpr int WCHP = (WCH + 255) / 256 * 256;      // LDS image, whole 1-KiB DMA pieces
-    static constexpr int WPIECES = WCHP / 256;                // 64 lanes x 16 B each
-    static constexpr int WPW = (WPIECES + MW * NW - 1) / (MW * NW);   // pieces per wave
-    static constexpr int BUF = STRIP + WCHP;
+    static constexpr int WF4 = (WCH / 4 + NTHR - 1) / NTHR;
+    static constexpr int BUF = STRIP + WCH;
     static_assert(STRIDE == 1 || ROWS % 2 == 0, "planes");
     static_assert(WCH % 4 == 0, "float4 weights");
 };
@@ -84,6 +82,7 @@ __global__ __launch_bounds__(64 * MW * NW, (MW * NW >= 8) ? 2 : 2) void tcn_conv
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
     float4 sreg[Cfg::SF4];
+    float4 wreg[Cfg::WF4];
 
     // global -> registers: raw loads only, nothing waits on them before the MFMA phase
     auto load_regs = [&](int c) {
@@ -97,20 +96,11 @@ __global__ __launch_bounds__(64 * MW * NW, (MW * NW >= 8) ? 2 : 2) void tcn_conv
                 v = *reinterpret_cast<const float4*>(src + tin * 16 + (f & 3) * 4);
             sreg[k] = v;
         }
-    };
-
-    // packed weights of channel c: global -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per
-    // wave-instruction, no VGPRs, no ds_write).  The image is a straight copy, so the lane-linear
-    // destination is exactly right; the tail piece reads into the pad of the packed buffer.
-    auto load_w = [&](int c, float* buf) {
-        const float* wsrc = p.wp + (size_t)c * Cfg::WCH + lane * 4;
+        const float* wsrc = p.wp + (size_t)c * Cfg::WCH;
 #pragma unroll
-        for (int k = 0; k < Cfg::WPW; ++k) {
-            const int piece = k * (MW * NW) + wave;
-            if (piece < Cfg::WPIECES)
-                __builtin_amdgcn_global_load_lds(
-                    (const __attribute__((address_space(1))) void*)(wsrc + piece * 256),
-                    (__attribute__((address_space(3))) void*)(buf + Cfg::STRIP + piece * 256), 16, 0, 0);
+        for (int k = 0; k < Cfg::WF4; ++k) {
+            const int f = tid + k * Cfg::NTHR;
+            if (f < Cfg::WCH / 4) wreg[k] = *reinterpret_cast<const float4*>(wsrc + f * 4);
         }
     };
 
@@ -137,9 +127,14 @@ __global__ __launch_bounds__(64 * MW * NW, (MW * NW >= 8) ? 2 : 2) void tcn_conv
                 else dst = (lr & 1) * Cfg::PLANE + (lr >> 1) * 16 + (f & 3) * 4;
                 *reinterpret_cast<float4*>(buf + dst) = v;
             }
+        } else {
+            const int k = item - Cfg::SF4;
+            const int f = tid + k * Cfg::NTHR;
+            if (f < Cfg::WCH / 4)
+                *reinterpret_cast<float4*>(buf + Cfg::STRIP + f * 4) = wreg[k];
         }
     };
-    constexpr int NITEM = Cfg::SF4;
+    constexpr int NITEM = Cfg::SF4 + Cfg::WF4;
 
     // One channel: KS k-steps of NT MFMAs.  LDS operand reads run PF k-steps ahead of the MFMAs
     // that use them, and the register -> LDS writes of the NEXT channel's staging ride between the
@@ -167,7 +162,9 @@ __global__ __launch_bounds__(64 * MW * NW, (MW * NW >= 8) ? 2 : 2) void tcn_conv
                 if (q < Cfg::NB) b[q] = bs[q * BSTEP];
             }
             const int item = m - (KS - NITEM);                          // staging rides the last k-steps
+#if TCN_PROBE != 1 && TCN_PROBE != 4
             if (more && item >= 0 && item < NITEM) store_item(nxt, item, sc, sh);
+#endif
 #pragma unroll
             for (int i = 0; i < NT; ++i) {
                 const int q = (STRIDE == 1) ? (i + m) : (2 * i + m);
@@ -187,7 +184,6 @@ __global__ __launch_bounds__(64 * MW * NW, (MW * NW >= 8) ? 2 : 2) void tcn_conv
         float sc, sh;
         scale_of(0, sc, sh);
         load_regs(0);
-        load_w(0, smem);
 #pragma unroll
         for (int it = 0; it < NITEM; ++it) store_item(smem, it, sc, sh);
     }
@@ -199,7 +195,9 @@ __global__ __launch_bounds__(64 * MW * NW, (MW * NW >= 8) ? 2 : 2) void tcn_conv
             const bool more = (c + 1) < p.Cin;
             float sc, sh;
             scale_of(c + 1, sc, sh);
-            if (more) { load_regs(c + 1); load_w(c + 1, nxt); }
+#if TCN_PROBE != 1 && TCN_PROBE != 5
+            if (more) load_regs(c + 1);
+#endif
             compute(cur, nxt, more, sc, sh);
             __syncthreads();
         }
@@ -210,7 +208,6 @@ __global__ __launch_bounds__(64 * MW * NW, (MW * NW >= 8) ? 2 : 2) void tcn_conv
             float sc, sh;
             scale_of(c + 1, sc, sh);
             load_regs(c + 1);
-            load_w(c + 1, nxt);
 #pragma unroll
             for (int it = 0; it < NITEM; ++it) store_item(nxt, it, sc, sh);
             __syncthreads();
@@ -335,7 +332,7 @@ int launch_tcn(const TcnParams& p, hipStream_t st) {
 extern "C" size_t step_tcn_packed_elems(int Co, int Ci, int Kt, int stride, int pack_mode) {
     PackGeom g;
     if (Co < 1 || Ci < 1 || !pack_geom(Co, Ci, Kt, stride, pack_mode, &g)) return 0;
-    return (size_t)g.cin_g * 2 * g.ks * g.ph * g.cpad + 256;   // + pad for the last DMA piece
+    return (size_t)g.cin_g * 2 * g.ks * g.ph * g.cpad;
 }
 
 extern "C" int step_tcn_pack_weight(const float* w, float* wp, int Co, int Ci, int Kt, int stride,
