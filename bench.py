@@ -126,6 +126,7 @@ def main():
     ap.add_argument("--frames", type=int, default=240)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-kernels", action="store_true")
+    ap.add_argument("--no-infer", action="store_true")
     args = ap.parse_args()
 
     from step_amd import parallel
@@ -171,8 +172,10 @@ def main():
     seq_per_s = args.batch * world * args.steps / dt
 
     # forward-only (eval, fused epilogues) rate of the same tensor, for reference
+    infer = 0.0
     model.eval()
     with torch.no_grad():
+      if not args.no_infer:
         model(x)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
@@ -187,8 +190,18 @@ def main():
         torch.cuda.empty_cache()
         kernels = time_kernels(args.batch, args.frames, device)
         dom = max(kernels, key=lambda k: k["ms"])
+        traffic = None
+        try:    # HBM bytes per launch from the committed PMC passes (same shape, N=4096 only)
+            with open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")) as fh:
+                pmc = json.load(fh)
+            if args.batch == 4096 and args.frames == 240 and dom["kernel"] in pmc:
+                traffic = pmc[dom["kernel"]]["hbm_bytes"]
+        except (OSError, ValueError):
+            pass
         roof = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"],
-                "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": dom["frac"], "traffic": None}
+                "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": dom["frac"], "traffic": traffic,
+                "flops_per_launch": tcn_flops(args.batch, dom["C"], (args.frames - 1) // 2 + 1
+                                              if dom["kernel"].endswith(("b1", "b2")) else args.frames)}
     cpu = None
     if rank == 0 and not args.no_cpu:
         cpu = cpu_baseline(args.frames)
