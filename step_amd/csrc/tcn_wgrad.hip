@@ -20,7 +20,10 @@ namespace {
 
 constexpr int WG_TT = 8;                    // output frames per staged chunk
 constexpr int WG_POS = WG_TT * 16;          // 128 positions
-constexpr int WG_DS = WG_POS + 1;           // odd row stride of the dout tile
+constexpr int WG_DS = WG_POS + 4;           // dout tile row stride: 16-B aligned rows (float4 writes),
+                                            // 4-way conflict on the (rare) A reads
+constexpr int WG_VS = 18;                   // floats per staged activation frame: 16 joints + 2 pad
+                                            // (8-B aligned rows, 2-way conflict on B reads)
 
 struct WgParams {
     const float* dout;
@@ -40,13 +43,15 @@ struct WgCfg {
     static constexpr int QW = 4 / MW;                         // column groups (waves) per block
     static constexpr int QB = QW * NQ * 32;                   // q's per block
     static constexpr int RW = STRIDE * (WG_TT - 1) + KT;      // staged input rows per chunk
-    static constexpr int RS = RW + ((KT - RW) % 32 + 32) % 32;   // >= RW and == KT (mod 32)
+    // channel stride of the strip image [channel][frame][WG_VS]: >= RW frames and
+    // == KT*WG_VS (mod 32) so a column tile straddling two channels keeps its bank sequence
+    static constexpr int RS = RW * WG_VS + (((KT - RW) * WG_VS) % 32 + 32) % 32;
     static constexpr int NCH0 = (QB + KT - 1) / KT + 1;
     static constexpr int NCH = NCH0 < 32 * MW ? NCH0 : 32 * MW;  // never more than Ci channels
-    static constexpr int VS = NCH * RS + 1;
     static constexpr int A_ITEMS = NCH * RW * 4;              // float4 items of the strip
     static constexpr int D_ITEMS = 32 * MW * 32;
-    static constexpr int LDS_FLOATS = 32 * MW * WG_DS + 16 * VS;
+    static constexpr int LDS_FLOATS = (32 * MW * WG_DS + NCH * RS + 3) / 4 * 4;
+    static_assert(RS % 2 == 0, "8-byte aligned channel stride");
 };
 
 // Software-pipelined variant (DB = true, used when two LDS images fit): while the 320 MFMAs of
@@ -85,7 +90,7 @@ __global__ __launch_bounds__(256) void tcn_wgrad_kernel(WgParams p) {
         int q = q0 + (qw * NQ + i) * 32 + l31;
         if (q >= p.Q) q = p.Q - 1;                   // clamp: result discarded at the store
         const int ci = q / KT;
-        bcol[i] = 32 * MW * WG_DS + (ci - ch0) * C::RS + (q - ci * KT) + half * C::VS;
+        bcol[i] = 32 * MW * WG_DS + (ci - ch0) * C::RS + (q - ci * KT) * WG_VS + half;
     }
     const int aoff = (mw * 32 + l31) * WG_DS + half;
 
@@ -139,8 +144,7 @@ __global__ __launch_bounds__(256) void tcn_wgrad_kernel(WgParams p) {
             const int item = step * DPS + k;
             if (item < DN) {
                 const int f = tid + item * 256;
-                float* d = img + (f >> 5) * WG_DS + (f & 31) * 4;
-                d[0] = dv[k].x; d[1] = dv[k].y; d[2] = dv[k].z; d[3] = dv[k].w;
+                *reinterpret_cast<float4*>(img + (f >> 5) * WG_DS + (f & 31) * 4) = dv[k];
             }
         }
 #pragma unroll
@@ -163,8 +167,9 @@ __global__ __launch_bounds__(256) void tcn_wgrad_kernel(WgParams p) {
                         v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
                     }
                 }
-                float* d = img + 32 * MW * WG_DS + (vq * 4) * C::VS + cil * C::RS + row;
-                d[0] = v.x; d[C::VS] = v.y; d[2 * C::VS] = v.z; d[3 * C::VS] = v.w;
+                float2* d = reinterpret_cast<float2*>(img + 32 * MW * WG_DS + cil * C::RS + row * WG_VS + vq * 4);
+                d[0] = make_float2(v.x, v.y);
+                d[1] = make_float2(v.z, v.w);
             }
         }
     };
@@ -176,7 +181,7 @@ __global__ __launch_bounds__(256) void tcn_wgrad_kernel(WgParams p) {
 #pragma unroll
             for (int i = 0; i < NQ; ++i)
                 acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(
-                    a, img[bcol[i] + STRIDE * tl + 2 * v2 * C::VS], acc[i], 0, 0, 0);
+                    a, img[bcol[i] + STRIDE * tl * WG_VS + 2 * v2], acc[i], 0, 0, 0);
         }
     };
 
