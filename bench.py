@@ -131,6 +131,9 @@ def main():
 
     from step_amd import parallel
     import torch.distributed as dist
+    if os.environ.get("STEP_BENCH_DEBUG"):
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["STEP_BENCH_DEBUG"]), exit=True)
     rank, local, world = parallel.init_from_env()
     if world != args.gpus and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)

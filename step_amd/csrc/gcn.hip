@@ -15,6 +15,7 @@
 // by each lane from the x tile in LDS with the <= EMAX non-zeros of column w of A_k held in
 // registers, so A lives entirely on chip.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -45,6 +46,7 @@ __global__ __launch_bounds__(256) void gcn_fwd_kernel(GcnParams p) {
     float* ellv = xs + p.Cip * GCN_P;                   // [K][EMAX][16]
     int* elli = reinterpret_cast<int*>(ellv + p.K * EMAX * 16);
     float* colsum = reinterpret_cast<float*>(elli + p.K * EMAX * 16);   // [K][16]
+    __shared__ int kcnt[4];                             // widest column list of each partition k
     float* bterm = colsum + p.K * 16;                   // [Copad][16]
     float* Wr = bterm + p.Copad * 16;                   // [Cip][Copad]   (if residual conv)
     float* br = Wr + (p.res_w ? p.Cip * p.Copad : 0);   // [Copad]
@@ -78,6 +80,8 @@ __global__ __launch_bounds__(256) void gcn_fwd_kernel(GcnParams p) {
         }
         for (int c = tid; c < p.Copad; c += 256) br[c] = (c < p.Co && p.res_b) ? p.res_b[c] : 0.f;
     }
+    if (tid < 4) kcnt[tid] = 1;
+    __syncthreads();
     if (tid < p.K * 16) {
         const int k = tid >> 4, w = tid & 15;
         int cnt = 0;
@@ -91,6 +95,7 @@ __global__ __launch_bounds__(256) void gcn_fwd_kernel(GcnParams p) {
                 ++cnt;
             }
         }
+        atomicMax(&kcnt[k], cnt);
         for (; cnt < EMAX; ++cnt) {
             ellv[(k * EMAX + cnt) * 16 + w] = 0.f;
             elli[(k * EMAX + cnt) * 16 + w] = 0;
@@ -148,17 +153,28 @@ __global__ __launch_bounds__(256) void gcn_fwd_kernel(GcnParams p) {
                     ai[e] = elli[(k * EMAX + e) * 16 + w16];
                 }
                 const float* wk = wrow + (size_t)k * p.Cip * p.Copad;
-                for (int cs = 0; cs < p.Cip / 2; ++cs) {
-                    const float* xr = xrow + cs * 2 * GCN_P;
-                    float z = 0.f;
+                // NE = the longest column list of A_k (block-uniform): the skeleton's partitions
+                // have 1 / 3 / 1 entries, so most of the EMAX slots are never touched
+                auto kphase = [&](auto ne_tag) {
+                    constexpr int NE = decltype(ne_tag)::value;
+                    for (int cs = 0; cs < p.Cip / 2; ++cs) {
+                        const float* xr = xrow + cs * 2 * GCN_P;
+                        float z = 0.f;
 #pragma unroll
-                    for (int e = 0; e < EMAX; ++e) z = fmaf(av[e], xr[ai[e]], z);
+                        for (int e = 0; e < NE; ++e) z = fmaf(av[e], xr[ai[e]], z);
 #pragma unroll
-                    for (int m = 0; m < MT; ++m) {
-                        const float a = wk[cs * 2 * p.Copad + m * 32];
-                        acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, z, acc[m], 0, 0, 0);
+                        for (int m = 0; m < MT; ++m) {
+                            const float a = wk[cs * 2 * p.Copad + m * 32];
+                            acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, z, acc[m], 0, 0, 0);
+                        }
                     }
-                }
+                };
+                const int ne = kcnt[k];
+                if (EMAX > 4 && ne > 4) kphase(std::integral_constant<int, EMAX>{});
+                else if (ne <= 1) kphase(std::integral_constant<int, 1>{});
+                else if (ne == 2) kphase(std::integral_constant<int, 2>{});
+                else if (ne == 3) kphase(std::integral_constant<int, 3>{});
+                else kphase(std::integral_constant<int, 4>{});
             }
             const int t = t0 + trow;
             if (t < p.T) {

@@ -136,6 +136,19 @@ __global__ __launch_bounds__(256) void gcn_bwd_data_kernel(GbParams p) {
     build_ell<EMAX>(p.A, p.K, ellv, elli, tid);
     build_row_ell<EMAX>(p.A, p.K, rellv, relli, tid);
     __syncthreads();
+    // longest column / row list of each partition (block-uniform): padded slots are skipped
+    int ccnt[3], rcnt[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        int c = 0, r = 0;
+        for (int e = 0; e < EMAX; ++e)
+            for (int w = 0; w < 16; ++w) {
+                if (ellv[(k * EMAX + e) * 16 + w] != 0.f) c = e + 1;
+                if (rellv[(k * EMAX + e) * 16 + w] != 0.f) r = e + 1;
+            }
+        ccnt[k] = __builtin_amdgcn_readfirstlane(c);
+        rcnt[k] = __builtin_amdgcn_readfirstlane(r);
+    }
 
     float av[3][EL], rv[3][EL];
     int ai[3][EL], ri[3][EL];
@@ -218,8 +231,8 @@ __global__ __launch_bounds__(256) void gcn_bwd_data_kernel(GbParams p) {
                             src = relli[(kq * EMAX + e) * 16 + w16] + lbase;
                         }
                         (void)a;
-                        dxa = fmaf(rw, __shfl(dz, src, 64), dxa);
-                        dAacc[kq][e] = fmaf(xrow[v], dz, dAacc[kq][e]);
+                        if (e < rcnt[kq]) dxa = fmaf(rw, __shfl(dz, src, 64), dxa);
+                        if (e < ccnt[kq]) dAacc[kq][e] = fmaf(xrow[v], dz, dAacc[kq][e]);
                     }
                     dxr[slot] += dxa;
                 }

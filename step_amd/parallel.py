@@ -17,6 +17,11 @@ def init_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal knobs (1-GPU box): STEP_DIST_BACKEND=gloo lets several ranks share one card,
+    # STEP_LOCAL_DEVICE pins every rank to that card
+    backend = backend or os.environ.get("STEP_DIST_BACKEND")
+    if "STEP_LOCAL_DEVICE" in os.environ:
+        local = int(os.environ["STEP_LOCAL_DEVICE"])
     if world > 1 and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
@@ -33,6 +38,30 @@ def shard_batch(n_total, rank, world):
     return start, start + base + (1 if rank < rem else 0)
 
 
+def _host_staged(group=None):
+    """gloo moves host memory: device tensors are staged through the CPU for it (rehearsal / CPU tests);
+    RCCL ('nccl') reduces device buffers in place over xGMI."""
+    return dist.get_backend(group) == "gloo"
+
+
+def _all_reduce_sum(flat, group=None):
+    if flat.is_cuda and _host_staged(group):
+        host = flat.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        flat.copy_(host)
+    else:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+
+
+def _broadcast(flat, src, group=None):
+    if flat.is_cuda and _host_staged(group):
+        host = flat.cpu()
+        dist.broadcast(host, src=src, group=group)
+        flat.copy_(host)
+    else:
+        dist.broadcast(flat, src=src, group=group)
+
+
 class GradBucket:
     """All parameters' gradients as ONE flat fp32 buffer -> a single all-reduce per step."""
 
@@ -46,7 +75,7 @@ class GradBucket:
             return
         grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.params]
         flat = torch.cat([g.reshape(-1) for g in grads])
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        _all_reduce_sum(flat, group)
         flat.div_(dist.get_world_size(group))
         off = 0
         for p, g in zip(self.params, grads):
@@ -60,8 +89,18 @@ class GradBucket:
 
 
 def broadcast_parameters(module, src=0, group=None):
-    """Make every rank start from rank `src`'s parameters and buffers."""
+    """Make every rank start from rank `src`'s parameters and buffers: one broadcast per dtype."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return
+    by_dtype = {}
     for t in list(module.parameters()) + list(module.buffers()):
-        dist.broadcast(t.data, src=src, group=group)
+        by_dtype.setdefault(t.dtype, []).append(t.data)
+    for dtype in sorted(by_dtype, key=str):
+        ts = by_dtype[dtype]
+        flat = torch.cat([t.reshape(-1) for t in ts])
+        _broadcast(flat, src, group)
+        off = 0
+        for t in ts:
+            n = t.numel()
+            t.copy_(flat[off:off + n].view_as(t))
+            off += n

@@ -222,3 +222,58 @@ def test_full_size_properties():
     assert_close(full[idx], ref, 1e-4, "probs")
     assert_close(feat[idx], rfeat, 1e-4, "feat")
     assert torch.allclose(full.sum(1).cpu(), torch.ones(512), atol=1e-5)
+
+
+@pytest.mark.parametrize("N,T,M", [(1, 37, 1), (3, 9, 1), (2, 101, 1), (2, 40, 2), (5, 75, 1)])
+def test_ragged_shapes_train_and_eval_vs_oracle(N, T, M):
+    """Edge shapes: N == 1, T not a multiple of the 8/40-frame tiles, T odd under stride 2,
+    T < Kt (kernel longer than the sequence), and M > 1 (persons folded into the batch)."""
+    from step_amd.net.classifier import Classifier
+    P = ckpt("ckpt_classifier_real_only_epoch395")
+    g = torch.Generator().manual_seed(N * 1000 + T)
+    x = torch.randn(N, 3, T, 16, M, generator=g) * 0.5
+    m = _load(Classifier(3, 4, {"strategy": "spatial"}), P).eval()
+    xo = x.permute(0, 4, 1, 2, 3).reshape(N * M, 3, T, 16, 1)       # oracle folds M itself
+    with torch.no_grad():
+        out, feat = m(x.to(D))
+        ref, rfeat = stgcn.classifier_forward({k: v.clone() for k, v in P.items()}, xo, "real_only")
+    if M == 1:
+        assert_close(out, ref, 1e-4, "eval probs")
+    else:
+        # the reference averages pooled features over M before fcn (classifier.py:82)
+        w = P["fcn.weight"].view(4, 64)
+        pooled = rfeat.view(N, M, 64).mean(1)
+        assert_close(out, torch.softmax(pooled @ w.t() + P["fcn.bias"], 1), 1e-4, "eval probs M>1")
+        return
+    if N == 1:
+        return                                   # batch-of-one BN statistics: eval only
+    labels = torch.arange(N) % 4
+    Pt = {k: v.clone() for k, v in P.items()}
+    loss_ref, out_ref, grads = stgcn.classifier_loss_and_grads(Pt, x, labels, "real_only")
+    m.train()
+    out, _ = m(x.to(D))
+    loss = F.cross_entropy(out, labels.to(D))
+    loss.backward()
+    assert abs(float(loss) - float(loss_ref)) < 2e-5
+    for k, p in m.named_parameters():
+        assert_grad_close(p.grad, grads[k], 1e-3, k, 2e-6 if feeds_train_bn(k) else 2e-7)
+
+
+def test_graph_conv_modules_standalone():
+    """ConvTemporalGraphical / ConvTransposeTemporalGraphical keep the reference call surface:
+    forward(x, A) -> (y, A), with autograd."""
+    from step_amd.net.utils.tgcn import ConvTemporalGraphical, ConvTransposeTemporalGraphical
+    from oracle import graph_adjacency
+    A = torch.tensor(graph_adjacency("spatial"), dtype=torch.float32)
+    for cls, tr in ((ConvTemporalGraphical, False), (ConvTransposeTemporalGraphical, True)):
+        torch.manual_seed(3)
+        mod = cls(5, 7, 3)
+        x = torch.randn(2, 5, 11, 16)
+        ref = stgcn.conv_temporal_graphical(x, A, mod.conv.weight.detach(), mod.conv.bias.detach(), tr)
+        mod = mod.to(D)
+        xg = x.to(D).requires_grad_(True)
+        y, A_out = mod(xg, A.to(D))
+        assert A_out.shape == A.shape
+        assert_close(y, ref, 1e-4, "y")
+        y.sum().backward()
+        assert xg.grad is not None and mod.conv.weight.grad is not None
