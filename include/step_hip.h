@@ -147,6 +147,24 @@ int step_tcn_conv(const float* in, const float* in_scale, const float* in_shift,
                   int N, int Ci, int Co, int Tin, int Tout, int Kt, int stride, int pack_mode,
                   void* stream);
 
+/* bf16-operand twins of the three entry points above (BASELINE config "classifier_stgcn_real_and_synth
+ * training, bf16"; same reference statements: classifier.py:156-162 and its input gradient).
+ * Tensors stay fp32 in HBM; activations (after `pre`) and weights are rounded to bf16 on their
+ * way into v_mfma_f32_32x32x16_bf16, accumulation and the epilogue are fp32.  Built for
+ * pack_mode 0 and 2, Kt = 75, channels 32 / 64 at stride 1 and 64 at stride 2 (every temporal
+ * conv of the three classifiers); step_tcn_packed_bytes_bf16 returns 0 for anything else and the
+ * caller keeps the fp32 entry points.                                                        */
+size_t step_tcn_packed_bytes_bf16(int Co, int Ci, int Kt, int stride, int pack_mode);
+int step_tcn_pack_weight_bf16(const float* w, void* wp, int Co, int Ci, int Kt, int stride,
+                              int pack_mode, void* stream);
+int step_tcn_conv_bf16(const float* in, const float* in_scale, const float* in_shift, int in_relu,
+                       const void* wp, const float* bias,
+                       const float* out_scale, const float* out_shift,
+                       const float* res, const float* res_scale, const float* res_shift,
+                       int out_relu, float* out,
+                       int N, int Ci, int Co, int Tin, int Tout, int Kt, int stride, int pack_mode,
+                       void* stream);
+
 /* weight gradient: dw[co][ci][j] = SUM_{n,t,v} dout[n,co,t,v] * a[n,ci,s*t+j-pad,v], with
  * a = relu?(in*in_scale+in_shift) recomputed on load; db[co] = SUM dout.  transposed != 0
  * writes the ConvTranspose2d layout (Ci,Co,Kt) instead.                                   */

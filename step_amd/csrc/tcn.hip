@@ -21,8 +21,13 @@
 // the channel's input strip (BN1 + ReLU applied on the way in, padding rows zero) and
 // the channel's packed weights into double-buffered LDS, one barrier per channel.
 #include "common.h"
+#include "tcn_pack.h"
 
 namespace {
+
+using step::PackGeom;
+using step::pack_geom;
+using step::pack_value;
 
 struct TcnParams {
     const float* in;
@@ -248,70 +253,15 @@ __global__ __launch_bounds__(64 * MW * NW, (MW * NW >= 8) ? 2 : 2) void tcn_conv
 }
 
 // ------------------------------------------------------------------ weight re-layout
-struct PackGeom {
-    int cin_g, cout_g, cpad, ph, ks, padL, stride_g;
-};
-
-// geometry of the generic form for each pack_mode (see step_hip.h)
-bool pack_geom(int Co, int Ci, int Kt, int stride, int mode, PackGeom* g) {
-    if (Kt < 1 || (Kt & 1) == 0) return false;
-    const int p = (Kt - 1) / 2;
-    g->ph = 1;
-    g->stride_g = 1;
-    g->ks = (Kt + 1) / 2;
-    g->padL = p;                               // Kt-1-p == p for odd Kt
-    switch (mode) {
-        case 0: g->cin_g = Ci; g->cout_g = Co; g->stride_g = stride; break;
-        case 1: if (stride != 1) return false; g->cin_g = Ci; g->cout_g = Co; break;
-        case 2:
-            g->cin_g = Co; g->cout_g = Ci;
-            if (stride == 2) {
-                g->ph = 2;
-                g->padL = p / 2;
-                int slots = 0;
-                for (int ph = 0; ph < 2; ++ph) {
-                    const int jmin = (ph + p) & 1;
-                    const int s = (ph + p + 2 * g->padL - jmin) / 2 + 1;
-                    slots = s > slots ? s : slots;
-                }
-                g->ks = (slots + 1) / 2;
-            } else if (stride != 1) return false;
-            break;
-        case 3: if (stride != 1) return false; g->cin_g = Co; g->cout_g = Ci; break;
-        default: return false;
-    }
-    if (stride != 1 && stride != 2) return false;
-    g->cpad = step::round_up(g->cout_g, 32);
-    return true;
-}
-
 __global__ void tcn_pack_kernel(const float* __restrict__ w, float* __restrict__ wp, int Co,
                                 int Ci, int Kt, int stride, int mode, PackGeom g) {
     const int mpad = g.ph * g.cpad;
     const int total = g.cin_g * 2 * g.ks * mpad;
-    const int p = (Kt - 1) / 2;
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
         const int m = e % mpad;
         const int jj = (e / mpad) % (2 * g.ks);
         const int cg = e / (mpad * 2 * g.ks);          // GEMM input channel
-        const int ph = m / g.cpad;
-        const int c = m % g.cpad;                      // GEMM output channel
-        float val = 0.f;
-        if (c < g.cout_g) {
-            if (mode == 0) {                           // w (Co,Ci,Kt): cg = ci, c = co
-                if (jj < Kt) val = w[((size_t)c * Ci + cg) * Kt + jj];
-            } else if (mode == 1) {                    // w (Ci,Co,Kt): cg = ci, c = co
-                if (jj < Kt) val = w[((size_t)cg * Co + c) * Kt + (Kt - 1 - jj)];
-            } else if (mode == 2) {                    // w (Co,Ci,Kt): cg = co, c = ci
-                int j;
-                if (stride == 1) j = Kt - 1 - jj;
-                else j = ph + p + 2 * g.padL - 2 * jj;
-                if (j >= 0 && j < Kt) val = w[((size_t)cg * Ci + c) * Kt + j];
-            } else {                                   // w (Ci,Co,Kt): cg = co, c = ci
-                if (jj < Kt) val = w[((size_t)c * Co + cg) * Kt + jj];
-            }
-        }
-        wp[e] = val;
+        wp[e] = pack_value(w, Co, Ci, Kt, stride, mode, g, cg, jj, m);
     }
 }
 

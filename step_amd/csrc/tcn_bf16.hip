@@ -1,0 +1,371 @@
+// Temporal (Kt x 1) convolution as a bf16 MFMA implicit GEMM with fp32 tensors in HBM.
+//
+// Same operator, generic form and epilogue as tcn.hip (tcn[2] of st_gcn,
+// classifier_stgcn_real_only/net/classifier.py:156-162, and its input gradient); the
+// activations and weights enter v_mfma_f32_32x32x16_bf16 as bf16, accumulation is fp32
+// (BASELINE config "classifier_stgcn_real_and_synth training, bf16").  Activations stay fp32
+// in HBM: they are converted on their way into LDS, after tcn[0]/tcn[1] (BN + ReLU).
+//
+// GEMM view per sequence: M = PH*Cpad output rows, N = (rho, v) positions, K = Cin * KT2
+// taps.  One MFMA contracts 16 INPUT CHANNELS of one tap:
+//   A[m][k]   = wgen[16g + k][jj][m]            packed per lane, read straight from L2
+//   B[k][col] = strip[16g + k][S*rho + jj][v]   col = (frame parity, joint)
+// The strip of a 16-channel group lies in LDS in the tensor's own order ([channel][frame][v],
+// bf16), so staging is a float4 load -> 4 x bf16 -> one 8-byte LDS write, and the B operand
+// is gathered channel-major by the transposing LDS read (ds_read_b64_tr_b16: 4 channels x 16
+// joints per 16 lanes).  As in tcn.hip the B fragment of (column tile i, tap jj) depends only
+// on 2*S*i + jj, so a wave keeps a sliding window of fragments and reads each once.
+#include "common.h"
+#include "tcn_pack.h"
+
+namespace {
+
+using step::PackGeom;
+using step::pack_geom;
+using step::pack_value;
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) bf16x4* lds_bf16x4_ptr;
+
+struct TbParams {
+    const float* in;
+    const float* in_scale;
+    const float* in_shift;
+    const bf16x8* wp;
+    const float* bias;
+    const float* out_scale;
+    const float* out_shift;
+    const float* res;
+    const float* res_scale;
+    const float* res_shift;
+    float* out;
+    int in_relu, out_relu;
+    int N, Cin, Cout, Cpad, PH, Tin, Tout, R, padL, nRB, G;
+};
+
+constexpr int NPROD = 4;          // staging waves per block
+
+template <int NT, int KT2, int STRIDE, int MW, int NW>
+struct TbCfg {
+    static constexpr int NCONS = MW * NW;                     // MFMA waves
+    static constexpr int NTHR = 64 * (NCONS + NPROD);
+    static constexpr int PTHR = 64 * NPROD;
+    static constexpr int RB = NW * NT * 2;                    // rho rows per tile
+    static constexpr int ROWS = STRIDE * (RB - 1) + KT2;      // staged input frames
+    // bytes between channels of the strip: == 64 (mod 256), which spreads the 4 channel rows
+    // of a transposing read (and the neighbouring frame's 4) over all 64 banks
+    static constexpr int CHS = ((ROWS * 32 - 64 + 255) / 256) * 256 + 64;
+    static constexpr int STRIP_BYTES = 16 * CHS;
+    static constexpr int LDS_BYTES = 2 * STRIP_BYTES;         // double-buffered
+    static constexpr int ITEMS = 16 * ROWS * 4;               // float4 items of one group
+    static constexpr int SF4 = (ITEMS + PTHR - 1) / PTHR;
+    static constexpr int NBTOT = STRIDE * 2 * (NT - 1) + KT2; // B fragments of one group
+    static constexpr int NB0 = STRIDE * 2 * (NT - 1) + 1;     // ... needed by tap 0
+    static_assert(CHS >= ROWS * 32, "strip row");
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+    static_assert(NCONS == 4, "one MFMA wave per SIMD");
+};
+
+// Work item = (tile, 16-channel group).  A block is NCONS MFMA waves (one per SIMD, MW M tiles
+// x NW column groups of NT column tiles) plus NPROD staging waves; it walks its tiles
+// persistently.  While the MFMA waves contract item i out of one LDS strip, the staging waves
+// bring item i+1 (next group, or the next tile's first group) into the other: HBM -> registers
+// -> BN + ReLU -> bf16 -> LDS.  One barrier per item; the two roles never touch the same buffer
+// between barriers, and the staging loads never sit in front of the MFMA waves' operand loads.
+template <int NT, int KT2, int STRIDE, int MW, int NW>
+__global__ __launch_bounds__(64 * (MW * NW + NPROD)) void tcn_bf16_kernel(TbParams p) {
+    using Cfg = TbCfg<NT, KT2, STRIDE, MW, NW>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ntiles = p.N * p.nRB;
+    // blocks that share an XCD (blockIdx % 8) take neighbouring tiles: their halos overlap in L2
+    int lb = blockIdx.x;
+    if ((gridDim.x & 7) == 0) lb = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+
+    if (wave >= Cfg::NCONS) {
+        // ------------------------------------------------------------ staging waves
+        const int ptid = tid - 64 * Cfg::NCONS;
+        float4 sreg[Cfg::SF4];
+        // HBM -> registers (raw); the loads stay in flight across the barrier
+        auto load_regs = [&](int tile, int g) {
+            const int n = tile / p.nRB;
+            const int tin0 = STRIDE * (tile % p.nRB) * Cfg::RB - p.padL;   // input frame of strip row 0
+#pragma unroll
+            for (int k = 0; k < Cfg::SF4; ++k) {
+                const int f = ptid + k * Cfg::PTHR;
+                const int c = f / (Cfg::ROWS * 4);
+                const int rem = f - c * (Cfg::ROWS * 4);
+                const int tin = tin0 + (rem >> 2);
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (f < Cfg::ITEMS && tin >= 0 && tin < p.Tin)
+                    v = *reinterpret_cast<const float4*>(
+                        p.in + (((size_t)n * p.Cin + 16 * g + c) * p.Tin + tin) * 16 + (rem & 3) * 4);
+                sreg[k] = v;
+            }
+        };
+        // registers -> tcn[0] scale/shift, tcn[1] ReLU -> bf16 -> LDS; padding frames stay exactly
+        // zero (the reference pads after the activation)
+        auto store_regs = [&](int tile, int g, char* buf) {
+            const int tin0 = STRIDE * (tile % p.nRB) * Cfg::RB - p.padL;
+#pragma unroll
+            for (int k = 0; k < Cfg::SF4; ++k) {
+                const int f = ptid + k * Cfg::PTHR;
+                if (f < Cfg::ITEMS) {
+                    const int c = f / (Cfg::ROWS * 4);
+                    const int rem = f - c * (Cfg::ROWS * 4);
+                    const int lr = rem >> 2;
+                    const int tin = tin0 + lr;
+                    f32x4 v = {sreg[k].x, sreg[k].y, sreg[k].z, sreg[k].w};
+                    if (tin >= 0 && tin < p.Tin) {
+                        if (p.in_scale) {
+                            const float sc = p.in_scale[16 * g + c], sh = p.in_shift[16 * g + c];
+                            v = v * sc + sh;
+                        }
+                        if (p.in_relu) {
+                            v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f);
+                            v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+                        }
+                    }
+                    *reinterpret_cast<bf16x4*>(buf + c * Cfg::CHS + lr * 32 + (rem & 3) * 8) =
+                        __builtin_convertvector(v, bf16x4);
+                }
+            }
+        };
+        // item sequence of this block: (tile, g) with g fastest
+        auto advance = [&](int& tile, int& g) {
+            if (++g == p.G) { g = 0; tile += gridDim.x; }
+        };
+        int t1 = lb, g1 = 0;                   // item whose registers are loaded / being stored
+        if (t1 < ntiles) { load_regs(t1, g1); store_regs(t1, g1, smem); }
+        advance(t1, g1);
+        if (t1 < ntiles) load_regs(t1, g1);    // item 1 in flight across the first barrier
+        __syncthreads();
+        int it = 0;
+        for (int tile = lb; tile < ntiles; tile += gridDim.x) {
+            for (int g = 0; g < p.G; ++g) {
+                // the MFMA waves work on item `it`; item it+1 goes to the other strip, and the
+                // loads of item it+2 are issued before the barrier so they fly during item it+1
+                if (t1 < ntiles) store_regs(t1, g1, smem + ((it + 1) & 1) * Cfg::STRIP_BYTES);
+                advance(t1, g1);
+                if (t1 < ntiles) load_regs(t1, g1);
+                __syncthreads();
+                ++it;
+            }
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------- MFMA waves
+    const int mw = wave / NW;
+    const int wn = wave % NW;
+    const int l31 = lane & 31;
+    const int half = lane >> 5;
+
+    // transposing-read address of this lane: channel row 8*half + q, frame (lane>>4)&1 of the
+    // column tile, joints 4p..4p+3  (q = (lane>>2)&3, p = lane&3)
+    const int boff = (8 * half + ((lane >> 2) & 3)) * Cfg::CHS +
+                     STRIDE * (2 * wn * NT + ((lane >> 4) & 1)) * 32 + (lane & 3) * 8;
+
+    f32x16 acc[NT];
+    constexpr int PFA = 6;      // taps of A-fragment prefetch (L2 latency)
+    constexpr int PFB = 2;      // taps of B-fragment prefetch (LDS latency)
+    auto compute = [&](int g, const char* buf) {
+        const bf16x8* wa = p.wp + ((size_t)g * KT2 * MW + mw) * 64 + lane;
+        const char* bb = buf + boff;
+        auto read_b = [&](int q) -> bf16x8 {
+            const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(bb + q * 32));
+            const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                (lds_bf16x4_ptr)(bb + 4 * Cfg::CHS + q * 32));
+            return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        };
+        bf16x8 a[KT2];
+        bf16x8 b[Cfg::NBTOT];
+#pragma unroll
+        for (int m = 0; m < PFA && m < KT2; ++m) a[m] = wa[m * MW * 64];
+#pragma unroll
+        for (int q = 0; q < Cfg::NB0 + PFB - 1 && q < Cfg::NBTOT; ++q) b[q] = read_b(q);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < KT2; ++j) {
+            if (j + PFA < KT2) a[j + PFA] = wa[(j + PFA) * MW * 64];
+            {
+                const int q = Cfg::NB0 + PFB - 1 + j;
+                if (q < Cfg::NBTOT) b[q] = read_b(q);
+            }
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[j], b[STRIDE * 2 * i + j], acc[i], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    int it = 0;
+    __syncthreads();
+    for (int tile = lb; tile < ntiles; tile += gridDim.x) {
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        for (int g = 0; g < p.G; ++g) {
+            compute(g, smem + (it & 1) * Cfg::STRIP_BYTES);
+            __syncthreads();
+            ++it;
+        }
+
+        // epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+        const int n = tile / p.nRB;
+        const int rho0 = (tile % p.nRB) * Cfg::RB;
+        const int v = l31 & 15;
+        const int trow = l31 >> 4;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = mw * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int ph = m / p.Cpad;
+            const int c = m - ph * p.Cpad;
+            if (c >= p.Cout || ph >= p.PH) continue;
+            const float bia = p.bias ? p.bias[c] : 0.f;
+            float osc = 1.f, osh = 0.f, rsc = 1.f, rsh = 0.f;
+            if (p.out_scale) { osc = p.out_scale[c]; osh = p.out_shift[c]; }
+            if (p.res && p.res_scale) { rsc = p.res_scale[c]; rsh = p.res_shift[c]; }
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                const int rho = rho0 + 2 * (wn * NT + i) + trow;
+                const int t = p.PH * rho + ph;
+                if (rho < p.R && t < p.Tout) {
+                    const size_t o = (((size_t)n * p.Cout + c) * p.Tout + t) * 16 + v;
+                    float val = (acc[i][r] + bia) * osc + osh;
+                    if (p.res) val += p.res[o] * rsc + rsh;
+                    if (p.out_relu) val = fmaxf(val, 0.f);
+                    p.out[o] = val;
+                }
+            }
+        }
+    }
+}
+
+// A fragments: [group g][tap jj][M tile][lane = 32*h + r][8] = wgen[16g + 8h + e][jj][32*mt + r]
+__global__ void tcn_pack_bf16_kernel(const float* __restrict__ w, __bf16* __restrict__ wp, int Co,
+                                     int Ci, int Kt, int stride, int mode, PackGeom g) {
+    const int mtiles = g.ph * g.cpad / 32;
+    const int kt2 = 2 * g.ks;
+    const int total = (g.cin_g / 16) * kt2 * mtiles * 512;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const int el = e & 7;
+        const int lane = (e >> 3) & 63;
+        const int mt = (e >> 9) % mtiles;
+        const int jj = ((e >> 9) / mtiles) % kt2;
+        const int grp = (e >> 9) / (mtiles * kt2);
+        const int cg = 16 * grp + 8 * (lane >> 5) + el;
+        const int m = 32 * mt + (lane & 31);
+        wp[e] = (__bf16)pack_value(w, Co, Ci, Kt, stride, mode, g, cg, jj, m);
+    }
+}
+
+bool bf16_supported(const PackGeom& g, int mode) {
+    if (mode != 0 && mode != 2) return false;
+    if (g.cin_g % 16 != 0) return false;
+    const int mw = g.ph * g.cpad / 32;
+    const int key = (2 * g.ks) * 100 + g.stride_g * 10 + mw;
+    switch (key) {
+        case 7611: case 7612: case 7622: case 3814: return true;
+        default: return false;
+    }
+}
+
+template <int NT, int KT2, int STRIDE, int MW, int NW>
+int launch_tb(const TbParams& p, hipStream_t st) {
+    using Cfg = TbCfg<NT, KT2, STRIDE, MW, NW>;
+    TbParams q = p;
+    q.nRB = step::ceil_div(p.R, Cfg::RB);
+    const long long tiles = (long long)p.N * q.nRB;
+    if (tiles <= 0 || tiles > 0x7fffffffLL) {
+        step::set_error("step_tcn_conv_bf16: %lld tiles out of range", tiles);
+        return STEP_ERR_ARG;
+    }
+    auto kern = tcn_bf16_kernel<NT, KT2, STRIDE, MW, NW>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+    int dev = 0, cus = 0;
+    if (e == hipSuccess) e = hipGetDevice(&dev);
+    if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (e != hipSuccess || cus < 1) {
+        step::set_error("step_tcn_conv_bf16: launch set-up (%d bytes of LDS): %s", Cfg::LDS_BYTES,
+                        hipGetErrorString(e));
+        return STEP_ERR_LAUNCH;
+    }
+    const unsigned blocks = tiles < cus ? (unsigned)tiles : (unsigned)cus;   // one block per CU (LDS)
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(Cfg::NTHR), Cfg::LDS_BYTES, st, q);
+    return step::check_launch("step_tcn_conv_bf16");
+}
+
+}  // namespace
+
+extern "C" size_t step_tcn_packed_bytes_bf16(int Co, int Ci, int Kt, int stride, int pack_mode) {
+    PackGeom g;
+    if (Co < 1 || Ci < 1 || !pack_geom(Co, Ci, Kt, stride, pack_mode, &g)) return 0;
+    if (!bf16_supported(g, pack_mode)) return 0;
+    return (size_t)(g.cin_g / 16) * 2 * g.ks * (g.ph * g.cpad / 32) * 512 * 2;
+}
+
+extern "C" int step_tcn_pack_weight_bf16(const float* w, void* wp, int Co, int Ci, int Kt, int stride,
+                                         int pack_mode, void* stream) {
+    PackGeom g;
+    STEP_REQUIRE(w && wp, "step_tcn_pack_weight_bf16: null pointer");
+    STEP_REQUIRE(Co >= 1 && Ci >= 1 && pack_geom(Co, Ci, Kt, stride, pack_mode, &g) &&
+                     bf16_supported(g, pack_mode),
+                 "step_tcn_pack_weight_bf16: unsupported Co=%d Ci=%d Kt=%d stride=%d mode=%d", Co, Ci, Kt,
+                 stride, pack_mode);
+    const int total = (g.cin_g / 16) * 2 * g.ks * (g.ph * g.cpad / 32) * 512;
+    const int blocks = step::ceil_div(total, 256) < 1024 ? step::ceil_div(total, 256) : 1024;
+    hipLaunchKernelGGL(tcn_pack_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w,
+                       reinterpret_cast<__bf16*>(wp), Co, Ci, Kt, stride, pack_mode, g);
+    return step::check_launch("step_tcn_pack_weight_bf16");
+}
+
+extern "C" int step_tcn_conv_bf16(const float* in, const float* in_scale, const float* in_shift,
+                                  int in_relu, const void* wp, const float* bias,
+                                  const float* out_scale, const float* out_shift, const float* res,
+                                  const float* res_scale, const float* res_shift, int out_relu,
+                                  float* out, int N, int Ci, int Co, int Tin, int Tout, int Kt,
+                                  int stride, int pack_mode, void* stream) {
+    PackGeom g;
+    STEP_REQUIRE(in && wp && out, "step_tcn_conv_bf16: null pointer");
+    STEP_REQUIRE(N >= 1 && Ci >= 1 && Co >= 1 && Tin >= 1 && Tout >= 1,
+                 "step_tcn_conv_bf16: bad shape N=%d Ci=%d Co=%d Tin=%d Tout=%d", N, Ci, Co, Tin, Tout);
+    STEP_REQUIRE(pack_geom(Co, Ci, Kt, stride, pack_mode, &g) && bf16_supported(g, pack_mode),
+                 "step_tcn_conv_bf16: unsupported Co=%d Ci=%d Kt=%d stride=%d mode=%d", Co, Ci, Kt, stride,
+                 pack_mode);
+    STEP_REQUIRE(Tout == (Tin - 1) / stride + 1,
+                 "step_tcn_conv_bf16: Tout=%d != (Tin-1)/stride+1 (Tin=%d)", Tout, Tin);
+    STEP_REQUIRE((in_scale == nullptr) == (in_shift == nullptr) &&
+                     (out_scale == nullptr) == (out_shift == nullptr) &&
+                     (res_scale == nullptr) == (res_shift == nullptr),
+                 "step_tcn_conv_bf16: scale/shift must come in pairs");
+    TbParams p{};
+    p.in = in; p.in_scale = in_scale; p.in_shift = in_shift; p.in_relu = in_relu;
+    p.wp = reinterpret_cast<const bf16x8*>(wp); p.bias = bias; p.out_scale = out_scale;
+    p.out_shift = out_shift; p.res = res; p.res_scale = res_scale; p.res_shift = res_shift;
+    p.out_relu = out_relu; p.out = out; p.N = N; p.Cin = g.cin_g; p.Cout = g.cout_g;
+    p.Cpad = g.cpad; p.PH = g.ph; p.padL = g.padL; p.G = g.cin_g / 16;
+    const bool dgrad = pack_mode >= 2;
+    p.Tin = dgrad ? Tout : Tin;                 // frames of the tensor being read
+    p.Tout = dgrad ? Tin : Tout;                // frames of the tensor being written
+    p.R = step::ceil_div(p.Tout, g.ph);
+    const int mw = g.ph * g.cpad / 32;
+    const int key = (2 * g.ks) * 100 + g.stride_g * 10 + mw;
+    hipStream_t st = (hipStream_t)stream;
+    switch (key) {
+        case 7611: return launch_tb<6, 76, 1, 1, 4>(p, st);
+        case 7612: return launch_tb<6, 76, 1, 2, 2>(p, st);
+        case 7622: return launch_tb<5, 76, 2, 2, 2>(p, st);
+        case 3814: return launch_tb<6, 38, 1, 4, 1>(p, st);
+        default: break;
+    }
+    step::set_error("step_tcn_conv_bf16: no kernel for Kt=%d stride=%d channels=%d", Kt, stride, g.cout_g);
+    return STEP_ERR_ARG;
+}

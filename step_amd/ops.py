@@ -93,7 +93,19 @@ def bn_backward(dy, x, mask_src, scale, shift, mask_mode, mean, invstd, gamma, t
 
 
 # --------------------------------------------------------------------- temporal conv
-def tcn_pack(w, Co, Ci, Kt, stride, mode):
+def tcn_bf16_supported(Co, Ci, Kt, stride, mode):
+    """True when the bf16-operand MFMA kernels cover this temporal conv (else use fp32)."""
+    return _lib.query("step_tcn_packed_bytes_bf16", Co, Ci, Kt, stride, mode) > 0
+
+
+def tcn_pack(w, Co, Ci, Kt, stride, mode, bf16=False):
+    if bf16:
+        nb = _lib.query("step_tcn_packed_bytes_bf16", Co, Ci, Kt, stride, mode)
+        if nb == 0:
+            raise _lib.StepHipError("no bf16 temporal kernel for C=%d Kt=%d stride=%d mode=%d" % (Co, Kt, stride, mode))
+        wp = torch.empty(nb, dtype=torch.uint8, device=w.device)
+        _lib.call("step_tcn_pack_weight_bf16", w, wp, Co, Ci, Kt, stride, mode)
+        return wp
     n = _lib.query("step_tcn_packed_elems", Co, Ci, Kt, stride, mode)
     if n == 0:
         raise _lib.StepHipError("temporal kernel Kt=%d stride=%d is not supported" % (Kt, stride))
@@ -103,13 +115,14 @@ def tcn_pack(w, Co, Ci, Kt, stride, mode):
 
 
 def tcn_conv(inp, in_scale, in_shift, in_relu, wp, bias, out_scale, out_shift, res, res_scale, res_shift,
-             out_relu, N, Ci, Co, Tin, Tout, Kt, stride, mode):
+             out_relu, N, Ci, Co, Tin, Tout, Kt, stride, mode, bf16=False):
     if mode < 2:
         out = torch.empty((N, Co, Tout, 16), dtype=torch.float32, device=inp.device)
     else:
         out = torch.empty((N, Ci, Tin, 16), dtype=torch.float32, device=inp.device)
-    _lib.call("step_tcn_conv", inp, in_scale, in_shift, int(in_relu), wp, bias, out_scale, out_shift, res,
-              res_scale, res_shift, int(out_relu), out, N, Ci, Co, Tin, Tout, Kt, stride, mode)
+    _lib.call("step_tcn_conv_bf16" if bf16 else "step_tcn_conv", inp, in_scale, in_shift, int(in_relu), wp,
+              bias, out_scale, out_shift, res, res_scale, res_shift, int(out_relu), out, N, Ci, Co, Tin, Tout,
+              Kt, stride, mode)
     return out
 
 

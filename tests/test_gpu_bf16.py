@@ -1,0 +1,87 @@
+"""GPU: the bf16-operand temporal kernels (BASELINE config 'real_and_synth training, bf16').
+
+Two bars per case: (a) against the oracle run on operands rounded to bf16 the way the kernel rounds
+them (after BN + ReLU; weights) the result must agree to fp32 round-off (1e-4) - this pins the
+kernel's indexing and accumulation exactly; (b) against the plain fp32 oracle it must stay within
+north_star's bf16 tolerance, 1e-2 relative."""
+import pytest
+import torch
+
+from oracle import stgcn
+from tests.util import assert_close
+
+pytestmark = pytest.mark.gpu
+TOL_EXACT = 1e-4
+TOL_BF16 = 1e-2
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rb(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+@pytest.mark.parametrize("C,stride,T,N", [
+    (64, 1, 48, 2), (64, 1, 23, 3), (32, 1, 96, 2), (32, 1, 17, 1), (64, 2, 41, 2), (64, 2, 80, 1),
+    (64, 1, 240, 1), (64, 2, 240, 1), (32, 1, 240, 1),
+])
+def test_tcn_bf16_forward_and_epilogue(C, stride, T, N):
+    from step_amd import ops
+    Kt = 75
+    assert ops.tcn_bf16_supported(C, C, Kt, stride, 0)
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(N, C, T, 16, generator=g)
+    w = torch.randn(C, C, Kt, 1, generator=g) * 0.05
+    b = torch.randn(C, generator=g)
+    sc, sh = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3
+    To = (T - 1) // stride + 1
+    a = torch.relu(x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    ref_exact = stgcn.temporal_conv(rb(a), rb(w), b, stride)
+    ref_f32 = stgcn.temporal_conv(a, w, b, stride)
+    d = dev()
+    wp = ops.tcn_pack(w.to(d), C, C, Kt, stride, 0, bf16=True)
+    out = ops.tcn_conv(x.to(d), sc.to(d), sh.to(d), True, wp, b.to(d), None, None, None, None, None,
+                       False, N, C, C, T, To, Kt, stride, 0, bf16=True)
+    assert_close(out, ref_exact, TOL_EXACT, "bf16 tcn vs bf16-rounded oracle")
+    assert_close(out, ref_f32, TOL_BF16, "bf16 tcn vs fp32 oracle")
+    osc, osh = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.2
+    res = torch.randn(N, C, To, 16, generator=g)
+    rsc, rsh = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.2
+    v = lambda t: t.view(1, -1, 1, 1)
+    ref2 = torch.relu(ref_exact * v(osc) + v(osh) + res * v(rsc) + v(rsh))
+    out2 = ops.tcn_conv(x.to(d), sc.to(d), sh.to(d), True, wp, b.to(d), osc.to(d), osh.to(d),
+                        res.to(d), rsc.to(d), rsh.to(d), True, N, C, C, T, To, Kt, stride, 0, bf16=True)
+    assert_close(out2, ref2, TOL_EXACT, "bf16 tcn fused epilogue")
+
+
+@pytest.mark.parametrize("C,stride,T,N", [(64, 1, 33, 2), (32, 1, 50, 2), (64, 2, 41, 2), (64, 2, 40, 1),
+                                          (64, 2, 240, 1), (64, 1, 120, 1)])
+def test_tcn_bf16_dgrad(C, stride, T, N):
+    from step_amd import ops
+    Kt = 75
+    assert ops.tcn_bf16_supported(C, C, Kt, stride, 2)
+    g = torch.Generator().manual_seed(12)
+    To = (T - 1) // stride + 1
+    w = torch.randn(C, C, Kt, 1, generator=g) * 0.05
+    du = torch.randn(N, C, To, 16, generator=g)
+
+    def dgrad(wt, dut):
+        a = torch.zeros(N, C, T, 16, requires_grad=True)
+        stgcn.temporal_conv(a, wt, None, stride).backward(dut)
+        return a.grad
+
+    d = dev()
+    wpd = ops.tcn_pack(w.to(d), C, C, Kt, stride, 2, bf16=True)
+    da = ops.tcn_conv(du.to(d), None, None, False, wpd, None, None, None, None, None, None, False,
+                      N, C, C, T, To, Kt, stride, 2, bf16=True)
+    assert_close(da, dgrad(rb(w), rb(du)), TOL_EXACT, "bf16 dgrad vs bf16-rounded oracle")
+    assert_close(da, dgrad(w, du), TOL_BF16, "bf16 dgrad vs fp32 oracle")
+
+
+def test_tcn_bf16_unsupported_shapes_say_so():
+    from step_amd import ops
+    assert not ops.tcn_bf16_supported(3, 3, 75, 1, 0)
+    assert not ops.tcn_bf16_supported(64, 64, 9, 1, 0)
+    assert not ops.tcn_bf16_supported(64, 64, 75, 1, 1)

@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--t", type=int, default=120)
     ap.add_argument("--kt", type=int, default=75)
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--bf16", action="store_true", help="bf16-operand MFMA kernels (fp32 tensors)")
     a = ap.parse_args()
     d = "cuda:0"
     n, c, s, tin, kt = a.n, a.c, a.stride, a.t, a.kt
@@ -30,13 +31,15 @@ def main():
     w = (torch.randn(c, c, kt, 1, generator=g) * 0.02).to(d)
     b = torch.zeros(c, device=d)
     sc, sh = torch.ones(c, device=d), torch.zeros(c, device=d)
-    wp = ops.tcn_pack(w, c, c, kt, s, 0)
-    wpd = ops.tcn_pack(w, c, c, kt, s, 2)
+    bf = a.bf16
+    wp = ops.tcn_pack(w, c, c, kt, s, 0, bf16=bf)
+    wpd = ops.tcn_pack(w, c, c, kt, s, 2, bf16=bf)
+    peak = 2500.0 if bf else 157.3
     calls = {
         "fwd": lambda: ops.tcn_conv(y, sc, sh, True, wp, b, None, None, None, None, None, False,
-                                    n, c, c, tin, tout, kt, s, 0),
+                                    n, c, c, tin, tout, kt, s, 0, bf16=bf),
         "dgrad": lambda: ops.tcn_conv(du, None, None, False, wpd, None, None, None, None, None, None,
-                                      False, n, c, c, tin, tout, kt, s, 2),
+                                      False, n, c, c, tin, tout, kt, s, 2, bf16=bf),
         "wgrad": lambda: ops.tcn_wgrad(du, y, sc, sh, True, n, c, c, tin, tout, kt, s, False, w.shape),
     }
     fl = 2.0 * c * c * kt * tout * 16 * n
@@ -52,8 +55,8 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / a.reps
-        print("%-6s C=%d s=%d Tin=%d N=%d: %8.3f ms  %7.2f TFLOP/s  %.3f of 157.3" %
-              (name, c, s, tin, n, ms, fl / ms / 1e9, fl / ms / 1e9 / 157.3), flush=True)
+        print("%-6s C=%d s=%d Tin=%d N=%d: %8.3f ms  %7.2f TFLOP/s  %.3f of %.1f" %
+              (name, c, s, tin, n, ms, fl / ms / 1e9, fl / ms / 1e9 / peak, peak), flush=True)
 
 
 if __name__ == "__main__":
