@@ -174,6 +174,16 @@ int step_tcn_wgrad(const float* dout, const float* in, const float* in_scale,
                    int N, int Ci, int Co, int Tin, int Tout, int Kt, int stride, int transposed,
                    void* ws, size_t ws_bytes, void* stream);
 
+/* bf16-operand twin of step_tcn_wgrad (dout and the recomputed activation rounded to bf16 on their
+ * way into the MFMA, fp32 accumulation; db stays an exact fp32 sum).  Built for Kt = 75, square
+ * 32- or 64-channel convs, stride 1 (and stride 2 at 64 channels); the ws_bytes helper returns 0
+ * for anything else and the caller keeps step_tcn_wgrad.  Writes the Conv2d layout (Co,Ci,Kt). */
+size_t step_tcn_wgrad_bf16_ws_bytes(int N, int Ci, int Co, int Tin, int Tout, int Kt, int stride);
+int step_tcn_wgrad_bf16(const float* dout, const float* in, const float* in_scale,
+                        const float* in_shift, int in_relu, float* dw, float* db,
+                        int N, int Ci, int Co, int Tin, int Tout, int Kt, int stride,
+                        void* ws, size_t ws_bytes, void* stream);
+
 /* ------------------------------------------------------------------- head ----------
  * F.avg_pool2d(x, x.size()[2:]) + mean over M=1, classifier.py:81-82                      */
 int step_pool_fwd(const float* x, float* feat, int N, int C, int inner, void* stream);

@@ -18,6 +18,11 @@ static inline int round_up(int a, int b) { return ceil_div(a, b) * b; }
 // hipGetLastError after a launch -> status
 int check_launch(const char* what);
 
+// ordered sum of the per-slice weight-gradient slabs [nsplit][Co][Ci*Kt] (+ [nsplit][Co] bias
+// partials) into dw / db; shared by the fp32 and bf16 wgrad kernels (tcn_wgrad.hip)
+int wgrad_reduce(const float* slab, const float* dbslab, float* dw, float* db, int Co, int Ci, int Kt,
+                 int nsplit, int transposed, hipStream_t st, const char* what);
+
 }  // namespace step
 
 #define STEP_REQUIRE(cond, ...)                         \

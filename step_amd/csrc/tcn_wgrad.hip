@@ -330,6 +330,14 @@ int launch_wg(const WgParams& p, const WgGeom& g, hipStream_t st) {
 
 }  // namespace
 
+int step::wgrad_reduce(const float* slab, const float* dbslab, float* dw, float* db, int Co, int Ci, int Kt,
+                       int nsplit, int transposed, hipStream_t st, const char* what) {
+    const int total = Co * Ci * Kt + Co;
+    hipLaunchKernelGGL(tcn_wgrad_reduce_kernel, dim3(step::ceil_div(total, 256)), dim3(256), 0, st, slab,
+                       dbslab, dw, db, Co, Ci, Kt, nsplit, transposed);
+    return step::check_launch(what);
+}
+
 extern "C" size_t step_tcn_wgrad_ws_bytes(int N, int Ci, int Co, int Tin, int Tout, int Kt) {
     WgGeom g;
     (void)Tin; (void)Tout;
@@ -374,8 +382,6 @@ extern "C" int step_tcn_wgrad(const float* dout, const float* in, const float* i
         case 922: rc = launch_wg<2, 5, 9, 2>(p, g, st); break;
     }
     if (rc) return rc;
-    const int total = Co * Ci * Kt + Co;
-    hipLaunchKernelGGL(tcn_wgrad_reduce_kernel, dim3(step::ceil_div(total, 256)), dim3(256), 0, st,
-                       p.slab, p.dbslab, dw, db, Co, Ci, Kt, g.nsplit, transposed);
-    return step::check_launch("step_tcn_wgrad(reduce)");
+    return step::wgrad_reduce(p.slab, p.dbslab, dw, db, Co, Ci, Kt, g.nsplit, transposed, st,
+                              "step_tcn_wgrad(reduce)");
 }

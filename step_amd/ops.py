@@ -98,6 +98,10 @@ def tcn_bf16_supported(Co, Ci, Kt, stride, mode):
     return _lib.query("step_tcn_packed_bytes_bf16", Co, Ci, Kt, stride, mode) > 0
 
 
+def tcn_wgrad_bf16_supported(Co, Ci, Kt, stride):
+    return _lib.query("step_tcn_wgrad_bf16_ws_bytes", 1, Ci, Co, 1, 1, Kt, stride) > 0
+
+
 def tcn_pack(w, Co, Ci, Kt, stride, mode, bf16=False):
     if bf16:
         nb = _lib.query("step_tcn_packed_bytes_bf16", Co, Ci, Kt, stride, mode)
@@ -126,12 +130,21 @@ def tcn_conv(inp, in_scale, in_shift, in_relu, wp, bias, out_scale, out_shift, r
     return out
 
 
-def tcn_wgrad(dout, inp, in_scale, in_shift, in_relu, N, Ci, Co, Tin, Tout, Kt, stride, transposed, wshape):
+def tcn_wgrad(dout, inp, in_scale, in_shift, in_relu, N, Ci, Co, Tin, Tout, Kt, stride, transposed, wshape,
+              bf16=False):
     dev = dout.device
-    nb = _lib.query("step_tcn_wgrad_ws_bytes", N, Ci, Co, Tin, Tout, Kt)
-    ws = _ws(nb, dev)
     dw = torch.empty(wshape, dtype=torch.float32, device=dev)
     db = torch.empty(Co, dtype=torch.float32, device=dev)
+    if bf16:
+        nb = _lib.query("step_tcn_wgrad_bf16_ws_bytes", N, Ci, Co, Tin, Tout, Kt, stride)
+        if nb == 0 or transposed:
+            raise _lib.StepHipError("no bf16 wgrad kernel for C=%d Kt=%d stride=%d" % (Co, Kt, stride))
+        ws = _ws(nb, dev)
+        _lib.call("step_tcn_wgrad_bf16", dout, inp, in_scale, in_shift, int(in_relu), dw, db, N, Ci, Co,
+                  Tin, Tout, Kt, stride, ws, nb)
+        return dw, db
+    nb = _lib.query("step_tcn_wgrad_ws_bytes", N, Ci, Co, Tin, Tout, Kt)
+    ws = _ws(nb, dev)
     _lib.call("step_tcn_wgrad", dout, inp, in_scale, in_shift, int(in_relu), dw, db, N, Ci, Co, Tin, Tout,
               Kt, stride, int(transposed), ws, nb)
     return dw, db

@@ -80,8 +80,41 @@ def test_tcn_bf16_dgrad(C, stride, T, N):
     assert_close(da, dgrad(w, du), TOL_BF16, "bf16 dgrad vs fp32 oracle")
 
 
+@pytest.mark.parametrize("C,stride,T,N", [(64, 1, 33, 2), (64, 1, 16, 5), (32, 1, 50, 3), (64, 2, 41, 2),
+                                          (64, 2, 40, 3), (64, 1, 240, 1), (32, 1, 240, 2), (64, 2, 240, 1),
+                                          (64, 1, 7, 300)])
+def test_tcn_bf16_wgrad(C, stride, T, N):
+    from step_amd import ops
+    Kt = 75
+    assert ops.tcn_wgrad_bf16_supported(C, C, Kt, stride)
+    g = torch.Generator().manual_seed(13)
+    To = (T - 1) // stride + 1
+    y = torch.randn(N, C, T, 16, generator=g)
+    sc, sh = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3
+    du = torch.randn(N, C, To, 16, generator=g)
+    a = torch.relu(y * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+
+    def wgrad(at, dut):
+        w = torch.zeros(C, C, Kt, 1, requires_grad=True)
+        b = torch.zeros(C, requires_grad=True)
+        stgcn.temporal_conv(at, w, b, stride).backward(dut)
+        return w.grad, b.grad
+
+    d = dev()
+    dw, db = ops.tcn_wgrad(du.to(d), y.to(d), sc.to(d), sh.to(d), True, N, C, C, T, To, Kt, stride, False,
+                           (C, C, Kt, 1), bf16=True)
+    dw_e, _ = wgrad(rb(a), rb(du))
+    dw_f, db_f = wgrad(a, du)
+    assert_close(dw, dw_e, TOL_EXACT, "bf16 wgrad vs bf16-rounded oracle")
+    assert_close(dw, dw_f, TOL_BF16, "bf16 wgrad vs fp32 oracle")
+    assert_close(db, db_f, TOL_EXACT, "bias gradient (exact fp32 sums)")
+
+
 def test_tcn_bf16_unsupported_shapes_say_so():
     from step_amd import ops
     assert not ops.tcn_bf16_supported(3, 3, 75, 1, 0)
     assert not ops.tcn_bf16_supported(64, 64, 9, 1, 0)
     assert not ops.tcn_bf16_supported(64, 64, 75, 1, 1)
+    assert not ops.tcn_wgrad_bf16_supported(3, 3, 75, 1)
+    assert not ops.tcn_wgrad_bf16_supported(64, 64, 9, 1)
+    assert not ops.tcn_wgrad_bf16_supported(32, 32, 75, 2)

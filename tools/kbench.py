@@ -40,7 +40,7 @@ def main():
                                     n, c, c, tin, tout, kt, s, 0, bf16=bf),
         "dgrad": lambda: ops.tcn_conv(du, None, None, False, wpd, None, None, None, None, None, None,
                                       False, n, c, c, tin, tout, kt, s, 2, bf16=bf),
-        "wgrad": lambda: ops.tcn_wgrad(du, y, sc, sh, True, n, c, c, tin, tout, kt, s, False, w.shape),
+        "wgrad": lambda: ops.tcn_wgrad(du, y, sc, sh, True, n, c, c, tin, tout, kt, s, False, w.shape, bf16=bf),
     }
     fl = 2.0 * c * c * kt * tout * 16 * n
     for name, fn in calls.items():
