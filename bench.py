@@ -27,6 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense (nominal clock)
 
 
 def make_model(device, kt=75):
@@ -56,11 +57,12 @@ def tcn_flops(n, c, t_out, kt=75):
     return 2.0 * c * c * kt * t_out * 16 * n
 
 
-def time_kernels(n, t, device, reps=3):
+def time_kernels(n, t, device, reps=3, bf16=False):
     """HIP-event timing of each temporal-conv kernel of the step (fwd, dgrad, wgrad x 3 blocks),
     launched alone on the current stream."""
     from step_amd import ops
     out = []
+    peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
     blocks = [(32, 1, t), (64, 2, t), (64, 1, (t - 1) // 2 + 1)]
     g = torch.Generator().manual_seed(7)
     for bi, (c, s, tin) in enumerate(blocks):
@@ -71,15 +73,15 @@ def time_kernels(n, t, device, reps=3):
         b = torch.zeros(c, device=device)
         sc = torch.ones(c, device=device)
         sh = torch.zeros(c, device=device)
-        wp = ops.tcn_pack(w, c, c, 75, s, 0)
-        wpd = ops.tcn_pack(w, c, c, 75, s, 2)
+        wp = ops.tcn_pack(w, c, c, 75, s, 0, bf16=bf16)
+        wpd = ops.tcn_pack(w, c, c, 75, s, 2, bf16=bf16)
         calls = {
             "tcn_fwd": lambda: ops.tcn_conv(y, sc, sh, True, wp, b, None, None, None, None, None, False,
-                                            n, c, c, tin, tout, 75, s, 0),
+                                            n, c, c, tin, tout, 75, s, 0, bf16=bf16),
             "tcn_dgrad": lambda: ops.tcn_conv(du, None, None, False, wpd, None, None, None, None, None,
-                                              None, False, n, c, c, tin, tout, 75, s, 2),
+                                              None, False, n, c, c, tin, tout, 75, s, 2, bf16=bf16),
             "tcn_wgrad": lambda: ops.tcn_wgrad(du, y, sc, sh, True, n, c, c, tin, tout, 75, s, False,
-                                               w.shape),
+                                               w.shape, bf16=bf16),
         }
         for name, fn in calls.items():
             fn()
@@ -94,7 +96,7 @@ def time_kernels(n, t, device, reps=3):
             fl = tcn_flops(n, c, tout)
             out.append({"kernel": "%s_b%d" % (name, bi), "C": c, "stride": s, "ms": round(ms, 3),
                         "tflops": round(fl / ms / 1e9, 2),
-                        "frac": round(fl / ms / 1e9 / PEAK_FP32_MFMA_TFLOPS, 4)})
+                        "frac": round(fl / ms / 1e9 / peak, 4)})
         del y, du
     return out
 
@@ -127,6 +129,10 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-kernels", action="store_true")
     ap.add_argument("--no-infer", action="store_true")
+    ap.add_argument("--mfma", choices=["f32", "bf16"], default="f32",
+                    help="MFMA operand type of the temporal convs for the headline number (f32 = BASELINE "
+                         "configs[1]); with f32 a short bf16-operand run is reported beside it")
+    ap.add_argument("--no-bf16", action="store_true", help="skip the secondary bf16-operand run")
     args = ap.parse_args()
 
     from step_amd import parallel
@@ -140,7 +146,8 @@ def main():
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
 
-    model = make_model(device).train()
+    import step_amd
+    model = step_amd.set_mfma_dtype(make_model(device).train(), args.mfma)
     parallel.broadcast_parameters(model)
     opt = torch.optim.Adam(model.parameters(), lr=0.1, weight_decay=1e-4)
     bucket = parallel.GradBucket(model.parameters())
@@ -160,19 +167,35 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tdt = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(tdt, op=dist.ReduceOp.MAX)
-        dt = float(tdt)
+    def timed(warmup, steps):
+        for _ in range(warmup):
+            step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        fence()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tdt = torch.tensor([dt], device=device, dtype=torch.float64)
+            dist.all_reduce(tdt, op=dist.ReduceOp.MAX)
+            dt = float(tdt)
+        return dt
+
+    dt = timed(args.warmup, args.steps)
     seq_per_s = args.batch * world * args.steps / dt
+
+    # the same step with bf16 MFMA operands in the temporal convs (BASELINE's bf16 training config)
+    bf16_run = None
+    if args.mfma == "f32" and not args.no_bf16:
+        step_amd.set_mfma_dtype(model, "bf16")
+        k = min(3, args.steps)
+        dtb = timed(1, k)
+        bf16_run = {"sequences_per_s": round(args.batch * world * k / dtb, 1),
+                    "ms_per_step": round(dtb / k * 1e3, 2), "steps": k,
+                    "note": "same model and step, temporal convs on v_mfma_f32_32x32x16_bf16 (fp32 tensors, "
+                            "fp32 accumulate); logits within 1e-2 of fp32 (tests/test_gpu_bf16.py)"}
+        step_amd.set_mfma_dtype(model, "f32")
 
     # forward-only (eval, fused epilogues) rate of the same tensor, for reference
     infer = 0.0
@@ -191,18 +214,18 @@ def main():
     if rank == 0 and not args.no_kernels:
         del x
         torch.cuda.empty_cache()
-        kernels = time_kernels(args.batch, args.frames, device)
+        kernels = time_kernels(args.batch, args.frames, device, bf16=(args.mfma == "bf16"))
         dom = max(kernels, key=lambda k: k["ms"])
         traffic = None
         try:    # HBM bytes per launch from the committed PMC passes (same shape, N=4096 only)
             with open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")) as fh:
                 pmc = json.load(fh)
-            if args.batch == 4096 and args.frames == 240 and dom["kernel"] in pmc:
+            if args.batch == 4096 and args.frames == 240 and args.mfma == "f32" and dom["kernel"] in pmc:
                 traffic = pmc[dom["kernel"]]["hbm_bytes"]
         except (OSError, ValueError):
             pass
         roof = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"],
-                "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": dom["frac"], "traffic": traffic,
+                "peak": PEAK_BF16_MFMA_TFLOPS if args.mfma == "bf16" else PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": dom["frac"], "traffic": traffic,
                 "flops_per_launch": tcn_flops(args.batch, dom["C"], (args.frames - 1) // 2 + 1
                                               if dom["kernel"].endswith(("b1", "b2")) else args.frames)}
     cpu = None
@@ -214,15 +237,17 @@ def main():
             "metric": "ST-GCN fwd+bwd sequences/sec", "value": round(seq_per_s, 1), "unit": "sequences/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": args.mfma, "data": "synthetic",
             "config": {"workload": "configs[1] tensor: real_only ST-GCN classifier (Kt=75, 3->32->64->64), "
-                                   "N=%d x 3 x %d x 16 per GPU, fp32; step = train-mode fwd + CrossEntropy + bwd "
-                                   "+ grad all-reduce + Adam" % (args.batch, args.frames),
+                                   "N=%d x 3 x %d x 16 per GPU, fp32 tensors%s; step = train-mode fwd + "
+                                   "CrossEntropy + bwd + grad all-reduce + Adam"
+                                   % (args.batch, args.frames,
+                                      ", bf16 MFMA operands in the temporal convs" if args.mfma == "bf16" else ""),
                        "global_batch": args.batch * world, "frames": args.frames,
                        "parallelism": "dp%d" % world},
             "inference_sequences_per_s_per_gpu": round(infer, 1),
             "step_tflops_per_gpu": round(9.30e9 * args.batch * args.steps / dt / 1e12, 2),
-            "roofline": roof, "kernels": kernels, "cpu_baseline": cpu,
+            "bf16_mfma": bf16_run, "roofline": roof, "kernels": kernels, "cpu_baseline": cpu,
         }
         print(json.dumps(line))
     if world > 1:

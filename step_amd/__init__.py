@@ -10,4 +10,19 @@ in include/step_hip.h).  There is no CPU fallback: CPU tensors raise.
 """
 from . import _lib  # noqa: F401
 
-__all__ = ["_lib"]
+
+def set_mfma_dtype(model, dtype):
+    """Choose the MFMA operand type of the temporal convolutions of every st_gcn block of `model`:
+    "f32" (default; 1e-4 parity with the reference) or "bf16" (BASELINE's bf16 training config:
+    operands rounded to bf16 inside the kernels, fp32 accumulation, fp32 tensors and parameters;
+    logits within 1e-2).  Blocks without a bf16 kernel (Kt != 75, 3 channels, st_gctn) stay fp32."""
+    if dtype not in ("f32", "bf16"):
+        raise ValueError("mfma dtype must be 'f32' or 'bf16', got %r" % (dtype,))
+    from .net.blocks import _StBlock
+    for m in model.modules():
+        if isinstance(m, _StBlock):
+            m.mfma_dtype = dtype
+    return model
+
+
+__all__ = ["_lib", "set_mfma_dtype"]

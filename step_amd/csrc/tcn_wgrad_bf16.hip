@@ -70,8 +70,12 @@ __global__ __launch_bounds__(512) void tcn_wgrad_bf16_kernel(WbParams p) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    const int qb = blockIdx.x % p.nqb;
-    const int split = blockIdx.x / p.nqb;
+    // blocks that share an XCD (blockIdx % 8) take the q-blocks of the same batch slices: they
+    // stream the same dout / activation chunks at the same time, out of that XCD's L2
+    int lb = blockIdx.x;
+    if ((gridDim.x & 7) == 0) lb = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const int qb = lb % p.nqb;
+    const int split = lb / p.nqb;
     const int tb = qb % p.ntb;                        // tap block
     const int ci0 = (qb / p.ntb) * 32;                // input-channel block
     const int j0 = tb * C::TAPS;

@@ -57,6 +57,7 @@ class _StBlock(nn.Module):
         self.relu = nn.ReLU(inplace=True)
         self._geom = (in_channels, out_channels, kernel_size[0], stride)
         self.a_nnz_max = 16
+        self.mfma_dtype = "f32"             # "bf16": step_amd.set_mfma_dtype(model, "bf16")
 
     @property
     def graph_conv(self):
@@ -66,7 +67,7 @@ class _StBlock(nn.Module):
         ci, co, kt, stride = self._geom
         bnr = self.residual[1] if self._res_kind == "conv" else None
         spec = BlockSpec(ci, co, kt, stride, self._res_kind, self.transposed, self.a_nnz_max,
-                         self.tcn[0], self.tcn[3], bnr, data_bn)
+                         self.tcn[0], self.tcn[3], bnr, data_bn, bf16=(self.mfma_dtype == "bf16"))
         g = self.graph_conv.conv
         params = []
         if data_bn is not None:

@@ -154,8 +154,13 @@ def tcn_wgrad(dout, inp, in_scale, in_shift, in_relu, N, Ci, Co, Tin, Tout, Kt, 
 class BlockSpec:
     """Static description of one st_gcn / st_gctn block plus its buffers (no grad)."""
 
-    def __init__(self, Ci, Co, Kt, stride, residual, transposed, nnz, bn1, bn2, bnr, data_bn=None):
+    def __init__(self, Ci, Co, Kt, stride, residual, transposed, nnz, bn1, bn2, bnr, data_bn=None,
+                 bf16=False):
         self.Ci, self.Co, self.Kt, self.stride = Ci, Co, Kt, stride
+        # bf16 MFMA operands for the temporal conv where those kernels exist (fp32 otherwise)
+        self.bf16_fwd = bool(bf16) and not transposed and tcn_bf16_supported(Co, Co, Kt, stride, 0)
+        self.bf16_dgrad = bool(bf16) and not transposed and tcn_bf16_supported(Co, Co, Kt, stride, 2)
+        self.bf16_wgrad = bool(bf16) and not transposed and tcn_wgrad_bf16_supported(Co, Co, Kt, stride)
         self.residual = residual            # 'none' | 'identity' | 'conv'
         self.transposed = transposed
         self.nnz = nnz
@@ -207,7 +212,8 @@ class StGcnBlockFn(torch.autograd.Function):
 
         m1, i1, s1, h1 = bn_prepare(y, 0, s.bn1, training)
         mode = 1 if s.transposed else 0
-        wp = tcn_pack(tcn_w, Co, Co, Kt, st, mode)
+        bf = s.bf16_fwd
+        wp = tcn_pack(tcn_w, Co, Co, Kt, st, mode, bf16=bf)
         mr = ir = sr = hr = None
         fused = (not training) and (not need_grad)
         if fused:
@@ -220,11 +226,11 @@ class StGcnBlockFn(torch.autograd.Function):
             elif s.residual == "identity":
                 res_t = x
             out = tcn_conv(y, s1, h1, True, wp, tcn_b, s2, h2, res_t, sr, hr, True,
-                           N, Co, Co, T, To, Kt, st, mode)
+                           N, Co, Co, T, To, Kt, st, mode, bf16=bf)
             return out
 
         u = tcn_conv(y, s1, h1, True, wp, tcn_b, None, None, None, None, None, False,
-                     N, Co, Co, T, To, Kt, st, mode)
+                     N, Co, Co, T, To, Kt, st, mode, bf16=bf)
         m2, i2, s2, h2 = bn_prepare(u, 0, s.bn2, training)
         res_t = None
         if s.residual == "conv":
@@ -260,11 +266,12 @@ class StGcnBlockFn(torch.autograd.Function):
             dr, dgr, dbr = bn_backward(dout, r, out, None, None, 1, mr, ir, bnr_w, training, 0)
 
         # temporal conv
-        dtw, dtb = tcn_wgrad(du, y, s1, h1, True, N, Co, Co, T, To, Kt, st, s.transposed, tcn_w.shape)
+        dtw, dtb = tcn_wgrad(du, y, s1, h1, True, N, Co, Co, T, To, Kt, st, s.transposed, tcn_w.shape,
+                             bf16=s.bf16_wgrad)
         dmode = 3 if s.transposed else 2
-        wpd = tcn_pack(tcn_w, Co, Co, Kt, st, dmode)
+        wpd = tcn_pack(tcn_w, Co, Co, Kt, st, dmode, bf16=s.bf16_dgrad)
         da = tcn_conv(du, None, None, False, wpd, None, None, None, None, None, None, False,
-                      N, Co, Co, T, To, Kt, st, dmode)
+                      N, Co, Co, T, To, Kt, st, dmode, bf16=s.bf16_dgrad)
         del du
 
         # BN1 + ReLU

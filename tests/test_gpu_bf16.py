@@ -118,3 +118,80 @@ def test_tcn_bf16_unsupported_shapes_say_so():
     assert not ops.tcn_wgrad_bf16_supported(3, 3, 75, 1)
     assert not ops.tcn_wgrad_bf16_supported(64, 64, 9, 1)
     assert not ops.tcn_wgrad_bf16_supported(32, 32, 75, 2)
+
+
+# ----------------------------------------------------------------------- whole models, bf16 MFMA
+def _load_models_helpers():
+    from tests.util import load_npz, sub, ckpt
+    return load_npz, sub, ckpt
+
+
+def test_bf16_classifier_eval_within_1e2_and_same_labels():
+    """north_star: logits within 1e-2 relative in bf16, identical classification."""
+    import step_amd
+    from step_amd.net import classifier, classifier_real_and_synth
+    load_npz, sub, ckpt = _load_models_helpers()
+    D = dev()
+    m = classifier.Classifier(3, 4, {"strategy": "spatial"})
+    m.load_state_dict(ckpt("ckpt_classifier_real_only_epoch395"))
+    m = step_amd.set_mfma_dtype(m.to(D).eval(), "bf16")
+    d = sub(load_npz("classifier_real_only_eval"), "")
+    with torch.no_grad():
+        probs, feat = m(d["h5_x"].to(D))
+        assert_close(probs, d["h5_probs"], TOL_BF16, "bf16 h5 probs")
+        assert_close(feat, d["h5_feat"], TOL_BF16, "bf16 h5 feat")
+        assert torch.equal(probs.argmax(1).cpu(), d["h5_probs"].argmax(1))
+        probs, feat = m(d["rnd_x"].to(D))
+        assert_close(probs, d["rnd_probs"], TOL_BF16, "bf16 rnd probs")
+        assert_close(feat, d["rnd_feat"], TOL_BF16, "bf16 rnd feat")
+
+    base = ckpt("ckpt_classifier_real_only_epoch395")
+    d = sub(load_npz("real_and_synth_eval_T240"), "")
+    P = {k: v for k, v in base.items() if not k.startswith("st_gcn_networks.0.residual")}
+    P.update({k[2:]: v for k, v in d.items() if k.startswith("P.")})
+    m = classifier_real_and_synth.Classifier(3, 4, {"strategy": "spatial"})
+    m.load_state_dict(P)
+    m = step_amd.set_mfma_dtype(m.to(D).eval(), "bf16")
+    with torch.no_grad():
+        o, f = m(d["x"].to(D))
+    assert_close(o, d["out"], TOL_BF16, "bf16 real_and_synth logits")
+    assert_close(f, d["feat"], TOL_BF16, "bf16 real_and_synth feat")
+
+
+def test_bf16_train_step_kt75_gradients_track_fp32_reference():
+    """One training step (ckpt395, Kt=75, train-mode BN) with bf16 MFMA operands against the fp32
+    reference fixture: loss and outputs within 1e-2; every stored gradient within 20 % in relative
+    L2 norm and pointing the same way (cosine > 0.99; measured: worst 14 % / 0.996) - bf16 rounding of activations/weights is
+    amplified by the batch-of-8 train-mode BatchNorm backward, so this is a tracking bound, not the
+    1e-2 forward bar."""
+    import torch.nn.functional as F
+    import step_amd
+    from step_amd.net import classifier
+    load_npz, sub, ckpt = _load_models_helpers()
+    D = dev()
+    d = sub(load_npz("train_steps"), "real_only_k75_ckpt395.")
+    m = classifier.Classifier(3, 4, {"strategy": "spatial"})
+    m.load_state_dict(ckpt("ckpt_classifier_real_only_epoch395"))
+    m = step_amd.set_mfma_dtype(m.to(D).train(), "bf16")
+    out, _ = m(d["x"].to(D))
+    loss = F.cross_entropy(out, d["labels"].to(D))
+    loss.backward()
+    assert abs(float(loss) - float(d["loss"])) < 1e-2 * max(1.0, abs(float(d["loss"])))
+    assert_close(out, d["out"], TOL_BF16, "bf16 train out")
+    checked, worst = 0, (0.0, "")
+    for k, p in m.named_parameters():
+        if "G." + k not in d:
+            continue
+        ref = d["G." + k].double().flatten()
+        got = p.grad.detach().cpu().double().flatten()
+        if float(ref.abs().max()) < 1e-6:
+            continue                                  # gradients that are zero up to round-off
+        rel = float((got - ref).norm() / ref.norm())
+        worst = max(worst, (rel, k))
+        cos = float(torch.dot(got, ref) / (got.norm() * ref.norm() + 1e-30))
+        assert rel <= 0.2, (k, rel)
+        if ref.numel() > 8:
+            assert cos > 0.99, (k, cos)
+        checked += 1
+    print("bf16 train step: %d gradients, worst relative L2 error %.4f (%s)" % (checked, worst[0], worst[1]))
+    assert checked >= 20
