@@ -13,6 +13,7 @@
 // Both kernels are persistent over (n, 8-frame) tiles and keep their reductions in registers;
 // per-block partials are summed in block order by a finalize kernel (bit-reproducible).
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -97,32 +98,47 @@ __device__ __forceinline__ float4 load_x4(const GbParams& p, int n, int ci, int 
 
 // ------------------------------------------------------------------ kernel 1: dx, dA
 // dz stays in the MFMA accumulators (column = (t, w) on the lane, row = (k, ci) in the
-// register).  dx needs SUM_w A[k,v,w] dz[.., w]: the 16 lanes of one frame exchange dz with
-// ds_bpermute along the row lists of A, so dx is produced in the same register layout and
-// stored straight to HBM (128-byte rows); nothing is scattered through LDS.
-template <int CIP, int COPAD, int EMAX>
+// register).
+//  dx needs SUM_w A[k,v,w] dz[.., w], a 16 x 16 product along the LANE axis inside each frame's
+//  16 lanes: it is taken as a sum over the 16 rotations of a DPP row (row_ror), each lane
+//  holding the coefficient A[k][its v][the w that rotation brings]; rotations whose coefficient
+//  vector is all zero (most of them: the skeleton's A has 46 non-zeros) are skipped with a
+//  block-uniform branch.  One VALU instruction per (register, live rotation), no LDS traffic,
+//  and dx comes out in the accumulator layout (128-byte rows to HBM).
+//  dA[k] = SUM x[ci,t,v] dz[(k,ci),(t,w)] is a (16 x K') x (K' x 16) product with K' = (ci, t):
+//  for one accumulator register the lane's (half, frame) pair is exactly the k index of
+//  v_mfma_f32_16x16x4_f32's B operand, so dz feeds it as it lies and the A operand is the
+//  lane's own x element; the dense 16 x 16 dA[k] accumulates in 4 registers per k.
+template <int R>
+__device__ __forceinline__ float row_ror(float x) {
+    if (R == 0) return x;
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x120 + (R & 15), 0xF, 0xF, false));
+}
+
+template <int R, int END, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (R < END) {
+        f(std::integral_constant<int, R>{});
+        static_for<R + 1, END>(f);
+    }
+}
+
+template <int CIP, int COPAD>
 __global__ __launch_bounds__(256) void gcn_bwd_data_kernel(GbParams p) {
     constexpr int KQ = 3 * CIP;
     constexpr int MQT = (KQ + 31) / 32;
     constexpr int KQP = MQT * 32;
     constexpr int MCI = (CIP + 31) / 32;            // ci tiles of the residual product
     constexpr int NDX = CIP >= 32 ? (CIP / 32) * 16 : 4;   // dx registers per lane
-    constexpr bool REG = EMAX <= 4;                  // adjacency lists live in registers
-    constexpr int EL = REG ? EMAX : 1;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Wq = smem;                                // [COPAD][KQP]   W[(k,c),ci] as [c][k*CIP+ci]
     float* dys = Wq + COPAD * KQP;                   // [COPAD][P]     dy tile, later the dres tile
     float* xs = dys + COPAD * P;                     // [CIP][P]       x tile, later Wr^T dres
-    float* ellv = xs + CIP * P;                      // [3][EMAX][16]  column lists
-    int* elli = reinterpret_cast<int*>(ellv + 3 * EMAX * 16);
-    float* rellv = reinterpret_cast<float*>(elli + 3 * EMAX * 16);   // row lists
-    int* relli = reinterpret_cast<int*>(rellv + 3 * EMAX * 16);
-    float* red = dys;                                // [4][3*EMAX*16], aliases dys after the loop
+    float* red = dys;                                // [4][3*16*16], aliases dys after the loop
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5, w16 = lane & 15;
     const int trow = 2 * wave + (l31 >> 4);
-    const int lbase = lane & ~15;
 
     for (int e = tid; e < COPAD * KQP; e += 256) {
         const int q = e % KQP, c = e / KQP;
@@ -133,41 +149,28 @@ __global__ __launch_bounds__(256) void gcn_bwd_data_kernel(GbParams p) {
                                : p.w[((size_t)k * p.Co + c) * p.Ci + ci];
         Wq[e] = v;
     }
-    build_ell<EMAX>(p.A, p.K, ellv, elli, tid);
-    build_row_ell<EMAX>(p.A, p.K, rellv, relli, tid);
-    __syncthreads();
-    // longest column / row list of each partition (block-uniform): padded slots are skipped
-    int ccnt[3], rcnt[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        int c = 0, r = 0;
-        for (int e = 0; e < EMAX; ++e)
-            for (int w = 0; w < 16; ++w) {
-                if (ellv[(k * EMAX + e) * 16 + w] != 0.f) c = e + 1;
-                if (rellv[(k * EMAX + e) * 16 + w] != 0.f) r = e + 1;
-            }
-        ccnt[k] = __builtin_amdgcn_readfirstlane(c);
-        rcnt[k] = __builtin_amdgcn_readfirstlane(r);
-    }
 
-    float av[3][EL], rv[3][EL];
-    int ai[3][EL], ri[3][EL];
-    if (REG) {
+    // rotation coefficients: cf[k][R] = A[k][v = this lane's joint][w = joint of the lane that
+    // row_ror:R brings here] (the source lane is found by rotating the lane ids themselves)
+    float cf[3][16];
+    unsigned rmask[3] = {0u, 0u, 0u};
+    static_for<0, 16>([&](auto rt) {
+        constexpr int R = decltype(rt)::value;
+        const int src = __float_as_int(row_ror<R>(__int_as_float(w16)));
 #pragma unroll
-        for (int k = 0; k < 3; ++k)
+        for (int k = 0; k < 3; ++k) {
+            const float a = (k < p.K) ? p.A[(k * 16 + w16) * 16 + src] : 0.f;
+            cf[k][R] = a;
+            if (__ballot(a != 0.f) != 0ull) rmask[k] |= 1u << R;
+        }
+    });
 #pragma unroll
-            for (int e = 0; e < EL; ++e) {
-                av[k][e] = ellv[(k * EMAX + e) * 16 + w16];
-                ai[k][e] = elli[(k * EMAX + e) * 16 + w16];
-                rv[k][e] = rellv[(k * EMAX + e) * 16 + w16];
-                ri[k][e] = relli[(k * EMAX + e) * 16 + w16] + lbase;
-            }
-    }
-    float dAacc[3][EMAX];
+    for (int k = 0; k < 3; ++k) rmask[k] = __builtin_amdgcn_readfirstlane(rmask[k]);
+
+    f32x4 dAk[3];
 #pragma unroll
-    for (int k = 0; k < 3; ++k)
-#pragma unroll
-        for (int e = 0; e < EMAX; ++e) dAacc[k][e] = 0.f;
+    for (int k = 0; k < 3; ++k) dAk[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
 
     for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
         const int n = tile / p.tiles_per_seq;
@@ -208,35 +211,39 @@ __global__ __launch_bounds__(256) void gcn_bwd_data_kernel(GbParams p) {
         float dxr[NDX];
 #pragma unroll
         for (int i = 0; i < NDX; ++i) dxr[i] = 0.f;
+        // register (m, r) holds row rr + 4*half of M tile m: partition kq, channel ci
+        static_for<0, 3>([&](auto kt) {
+            constexpr int kq = decltype(kt)::value;
+            // dA[kq] += x^T dz  (16x16x4: k index = the lane's (half, frame))
 #pragma unroll
-        for (int m = 0; m < MQT; ++m)
+            for (int m = 0; m < MQT; ++m)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rr = (r & 3) + 8 * (r >> 2);               // row without the lane half
-                const int kq = (m * 32 + rr) / CIP;                   // static for CIP in {8,32,64}
-                if (kq < 3) {
-                    const int ci = m * 32 + rr + 4 * half - kq * CIP;
-                    const int slot = CIP >= 32 ? ((m * 32) % CIP) / 32 * 16 + r : (r & 3);
-                    const float dz = acc[m][r];
-                    const float* xrow = xs + ci * P + trow * 16;
-                    float dxa = 0.f;
-#pragma unroll
-                    for (int e = 0; e < EMAX; ++e) {
-                        float a, rw;
-                        int v, src;
-                        if (REG) { a = av[kq][e]; v = ai[kq][e]; rw = rv[kq][e]; src = ri[kq][e]; }
-                        else {
-                            a = ellv[(kq * EMAX + e) * 16 + w16]; v = elli[(kq * EMAX + e) * 16 + w16];
-                            rw = rellv[(kq * EMAX + e) * 16 + w16];
-                            src = relli[(kq * EMAX + e) * 16 + w16] + lbase;
-                        }
-                        (void)a;
-                        if (e < rcnt[kq]) dxa = fmaf(rw, __shfl(dz, src, 64), dxa);
-                        if (e < ccnt[kq]) dAacc[kq][e] = fmaf(xrow[v], dz, dAacc[kq][e]);
+                for (int r = 0; r < 16; ++r) {
+                    const int rr = (r & 3) + 8 * (r >> 2);
+                    if ((m * 32 + rr) / CIP == kq) {
+                        const int ci = m * 32 + rr + 4 * half - kq * CIP;
+                        dAk[kq] = __builtin_amdgcn_mfma_f32_16x16x4f32(xs[ci * P + (trow & 7) * 16 + w16],
+                                                                       acc[m][r], dAk[kq], 0, 0, 0);
                     }
-                    dxr[slot] += dxa;
                 }
-            }
+            // dx += A_kq dz along the lanes of each frame
+            static_for<0, 16>([&](auto rt) {
+                constexpr int R = decltype(rt)::value;
+                if ((rmask[kq] >> R) & 1u) {
+                    const float c = cf[kq][R];
+#pragma unroll
+                    for (int m = 0; m < MQT; ++m)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int rr = (r & 3) + 8 * (r >> 2);
+                            if ((m * 32 + rr) / CIP == kq) {
+                                const int slot = CIP >= 32 ? ((m * 32) % CIP) / 32 * 16 + r : (r & 3);
+                                dxr[slot] = fmaf(c, row_ror<R>(acc[m][r]), dxr[slot]);
+                            }
+                        }
+                }
+            });
+        });
 
         // residual branch: dx[ci, s*t', w] += SUM_c Wr[c,ci] dres[c, t', w]   (through LDS: for
         // stride 2 the output columns of this product belong to other waves' frames)
@@ -301,21 +308,16 @@ __global__ __launch_bounds__(256) void gcn_bwd_data_kernel(GbParams p) {
         }
     }
 
-    // block partial of dA (ELL form): lanes with equal w -> wave -> block
+    // block partial of dA (dense 16 x 16 per k): D register i of lane l = dA[k][4*(l>>4)+i][l&15]
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < 3; ++k)
 #pragma unroll
-        for (int e = 0; e < EMAX; ++e) {
-            float v = dAacc[k][e];
-            v += __shfl_xor(v, 16, 64);
-            v += __shfl_xor(v, 32, 64);
-            if (lane < 16) red[wave * (3 * EMAX * 16) + (k * EMAX + e) * 16 + lane] = v;
-        }
+        for (int i = 0; i < 4; ++i)
+            red[wave * 768 + (k * 16 + 4 * (lane >> 4) + i) * 16 + w16] = dAk[k][i];
     __syncthreads();
-    for (int e = tid; e < 3 * EMAX * 16; e += 256)
-        p.part1[(size_t)blockIdx.x * (3 * EMAX * 16) + e] =
-            (red[e] + red[3 * EMAX * 16 + e]) + (red[2 * 3 * EMAX * 16 + e] + red[3 * 3 * EMAX * 16 + e]);
+    for (int e = tid; e < 768; e += 256)
+        p.part1[(size_t)blockIdx.x * 768 + e] = (red[e] + red[768 + e]) + (red[2 * 768 + e] + red[3 * 768 + e]);
 }
 
 // -------------------------------------------------------------- kernel 2: dW, S, dWr, dbr
@@ -532,16 +534,13 @@ __global__ void gcn_bwd_finalize_kernel(FinParams f) {
                 for (int b = 0; b < f.nblk2; ++b) S += f.part2[(size_t)b * PART + offS + c * 16 + w];
                 bias_part += f.b[k * f.Co + c] * S;
             }
-        int cnt = 0;
         for (int v = 0; v < 16; ++v) {
             const float a = f.A[(k * 16 + v) * 16 + w];
             float out = 0.f;
-            if (a != 0.f && cnt < f.emax) {
+            if (a != 0.f) {
                 float s = 0.f;
-                for (int b = 0; b < f.nblk1; ++b)
-                    s += f.part1[(size_t)b * (3 * f.emax * 16) + (k * f.emax + cnt) * 16 + w];
+                for (int b = 0; b < f.nblk1; ++b) s += f.part1[(size_t)b * 768 + (k * 16 + v) * 16 + w];
                 out = s + bias_part;
-                ++cnt;
             }
             f.dA[(k * 16 + v) * 16 + w] = out;
         }
@@ -577,8 +576,7 @@ bool gb_geom(int N, int Ci, int Co, int T, int nnz, GbGeom* g) {
     g->emax = nnz <= 4 ? 4 : 16;
     g->cir = g->cip <= 32 ? 32 : 64;
     const int kqp = ((3 * g->cip + 31) / 32) * 32;
-    g->lds1 = ((size_t)g->copad * kqp + (size_t)g->copad * P + (size_t)g->cip * P +
-               4 * 3 * (size_t)g->emax * 16) * 4;
+    g->lds1 = ((size_t)g->copad * kqp + (size_t)g->copad * P + (size_t)g->cip * P) * 4;
     g->lds2 = ((size_t)g->copad * PS + 2 * (size_t)g->cir * PS + 2 * 3 * (size_t)g->emax * 16) * 4;
     const long long ntiles = (long long)N * ((T + TT - 1) / TT);
     auto blocks = [&](size_t lds) {
@@ -589,14 +587,14 @@ bool gb_geom(int N, int Ci, int Co, int T, int nnz, GbGeom* g) {
     };
     g->nblk1 = blocks(g->lds1);
     g->nblk2 = blocks(g->lds2);
-    g->part1 = (size_t)3 * g->emax * 16;
+    g->part1 = (size_t)3 * 16 * 16;
     g->part2 = (size_t)3 * g->copad * g->cir + (size_t)g->copad * 16 + (size_t)g->copad * g->cir + g->copad;
     return g->lds1 <= 160 * 1024 && g->lds2 <= 160 * 1024;
 }
 
 template <int CIP, int COPAD, int EMAX>
 int launch_gb(const GbParams& p, const GbGeom& g, hipStream_t st) {
-    auto k1 = gcn_bwd_data_kernel<CIP, COPAD, EMAX>;
+    auto k1 = gcn_bwd_data_kernel<CIP, COPAD>;
     auto k2 = gcn_bwd_weight_kernel<CIP, COPAD, EMAX>;
     hipError_t e = hipSuccess;
     if (g.lds1 > 64 * 1024)
