@@ -207,6 +207,18 @@ int step_bn_rows_bwd(const float* dy, const float* x, const float* mean, const f
 int step_softmax_fwd(const float* x, float* y, int N, int O, void* stream);
 int step_softmax_bwd(const float* dy, const float* y, float* dx, int N, int O, void* stream);
 
+/* ------------------------------------------------------------- CVAE loss ----
+ * vae_loss = between_frame_loss(x_in, x_out) + beta * KLD(mean, lsig):
+ * generator_cvae/utils/losses.py:7-42 (a Python loop of scalar mse_loss calls in the reference) and
+ * generator_cvae/utils/processor_stgcn.py:34-40, value and gradients in one pass.
+ * x_in, x_out (N,C,T,V) (M = 1); mean, lsig (N,Z) or both NULL (between_frame_loss alone).
+ * loss[3] = {total, between_frame, KLD}; d_x_out (N,C,T,V), d_mean, d_lsig (N,Z) nullable
+ * (d loss / d x_in = -d_x_out).  ws: step_vae_loss_ws_bytes(N).  C*T*V <= 15360.             */
+size_t step_vae_loss_ws_bytes(int N);
+int step_vae_loss(const float* x_in, const float* x_out, const float* mean, const float* lsig, float beta,
+                  float* loss, float* d_x_out, float* d_mean, float* d_lsig,
+                  int N, int C, int T, int V, int Z, void* ws, size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -399,9 +399,60 @@ def gen_hybrid():
     save("real_and_synth_eval_T240", **out)
 
 
+# --------------------------------------------------------------------------- 9
+def gen_vae_loss():
+    """generator_cvae/utils/losses.py between_frame_loss and the vae_loss of
+    processor_stgcn.py:34-40 (between_frame_loss + KLD), values and autograd gradients.
+    losses.py calls ``np.int`` (removed in numpy 1.24); the alias it had is restored for the call."""
+    cv = ref_import("generator_cvae", "CVAE_stgcn")
+    losses = importlib.import_module("utils.losses")
+    if not hasattr(np, "int"):
+        np.int = int          # numpy < 1.24: ``np.int is int``
+    out = {}
+    torch.manual_seed(21)
+    for tag, (n, t) in {"a": (3, 12), "b": (2, 75), "c": (2, 1), "d": (1, 2), "e": (2, 3)}.items():
+        x_in = torch.rand(n, 3, t, 16, 1)
+        x_out = (x_in + 0.3 * torch.randn(n, 3, t, 16, 1)).requires_grad_(True)
+        mean = (torch.randn(n, 32) * 0.5).requires_grad_(True)
+        lsig = (torch.randn(n, 32) * 0.5).requires_grad_(True)
+        bf = losses.between_frame_loss(x_in, x_out)
+        kld = -0.5 * torch.sum(1 + lsig - mean.pow(2) - lsig.exp())
+        loss = bf + 1.0 * kld
+        loss.backward()
+        out.update({tag + ".x_in": x_in.numpy(), tag + ".x_out": x_out.detach().numpy(),
+                    tag + ".mean": mean.detach().numpy(), tag + ".lsig": lsig.detach().numpy(),
+                    tag + ".bf": np.float64(bf.item()), tag + ".loss": np.float64(loss.item()),
+                    tag + ".d_x_out": x_out.grad.numpy().copy(), tag + ".d_mean": mean.grad.numpy().copy(),
+                    tag + ".d_lsig": lsig.grad.numpy().copy()})
+    save("vae_loss", **out)
+
+    # one CVAE training forward/backward with the reference's own loss (ckpt105, T = 24)
+    ck = os.path.join(REF, "generator_cvae", "model_gait_cvae_stgcn", "features", "epoch105_model.pth.tar")
+    sd = torch.load(ck, map_location="cpu", weights_only=True)
+    model = cv.CVAE(3, 75, 16, 32, 4, {"strategy": "spatial"})
+    model.load_state_dict(sd)
+    model.train()
+    torch.manual_seed(22)
+    T = 24
+    x = torch.rand(3, 3, T, 16, 1)
+    onehot = torch.eye(4)[torch.tensor([2, 0, 3])]
+    lenc = onehot[:, :, None, None, None].repeat(1, 1, T, 16, 1)
+    mean, lsig = model.encoder(x, lenc)
+    eps = torch.randn(3, 32)
+    zz = eps * torch.exp(0.5 * lsig) + mean
+    rec = model.decoder(zz, onehot, T, 16)
+    bf = losses.between_frame_loss(x, rec)
+    loss = bf + (-0.5 * torch.sum(1 + lsig - mean.pow(2) - lsig.exp()))
+    loss.backward()
+    out = dict(x=x.numpy(), lenc=lenc.numpy(), onehot=onehot.numpy(), eps=eps.numpy(),
+               rec=rec.detach().numpy(), loss=np.float64(loss.item()), bf=np.float64(bf.item()))
+    _slim_grads("", {k: v.grad.numpy() for k, v in model.named_parameters()}, out)
+    save("cvae_vae_loss_train", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["graph", "gcn", "blocks", "ckpt", "train", "cvae", "hybrid"]
+    which = sys.argv[1:] or ["graph", "gcn", "blocks", "ckpt", "train", "cvae", "hybrid", "vae_loss"]
     fns = dict(graph=gen_graph, gcn=gen_gcn, blocks=gen_blocks, ckpt=gen_ckpt_and_eval,
-               train=gen_train_steps, cvae=gen_cvae, hybrid=gen_hybrid)
+               train=gen_train_steps, cvae=gen_cvae, hybrid=gen_hybrid, vae_loss=gen_vae_loss)
     for w in which:
         fns[w]()

@@ -201,3 +201,25 @@ def test_cvae_train_fwd_bwd():
             assert_grad_close(g, d["G." + k], 1e-3, k, 1e-6 if feeds_train_bn(k) else 1e-7)
         elif "Gsl." + k in d:
             assert_close(g[:2], d["Gsl." + k], 1e-3, k)
+
+
+# ---------------------------------------------------------------- CVAE loss
+@pytest.mark.parametrize("tag", list("abcde"))
+def test_vae_loss_oracle_vs_reference(tag):
+    """between_frame_loss + KLD (losses.py:7-42, processor_stgcn.py:34-40): value and gradients"""
+    from oracle import losses
+    d = sub(load_npz("vae_loss"), tag + ".")
+    x_out = d["x_out"].clone().requires_grad_(True)
+    mean = d["mean"].clone().requires_grad_(True)
+    lsig = d["lsig"].clone().requires_grad_(True)
+    bf = losses.between_frame_loss(d["x_in"], x_out)
+    loss = losses.vae_loss(d["x_in"], x_out, mean, lsig, 1.0)
+    loss.backward()
+    assert abs(float(bf) - float(d["bf"])) <= 2e-6 * max(1.0, abs(float(d["bf"])))
+    assert abs(float(loss) - float(d["loss"])) <= 2e-6 * max(1.0, abs(float(d["loss"])))
+    assert_close(x_out.grad, d["d_x_out"], 1e-5, "d_x_out")
+    assert_close(mean.grad, d["d_mean"], 1e-6, "d_mean")
+    assert_close(lsig.grad, d["d_lsig"], 1e-6, "d_lsig")
+    if d["x_in"].shape[2] <= 3:     # the reference's own statement order, term by term
+        ref = losses.between_frame_loss_loops(d["x_in"], d["x_out"])
+        assert abs(float(ref) - float(d["bf"])) <= 1e-6 * max(1.0, abs(float(d["bf"])))
