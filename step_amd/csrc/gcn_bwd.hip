@@ -40,50 +40,6 @@ struct GbParams {
 
 __device__ __forceinline__ int rowmap(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
-// row-v non-zeros of A_k (the transposed pattern) into LDS: rellv/relli[(k*EMAX+e)*16 + v] = (A[k,v,w], w)
-template <int EMAX>
-__device__ __forceinline__ void build_row_ell(const float* A, int K, float* rellv, int* relli, int tid) {
-    if (tid >= 64 && tid < 112) {
-        const int k = (tid - 64) >> 4, v = tid & 15;
-        int cnt = 0;
-        if (k < K)
-            for (int w = 0; w < 16; ++w) {
-                const float a = A[(k * 16 + v) * 16 + w];
-                if (a != 0.f && cnt < EMAX) {
-                    rellv[(k * EMAX + cnt) * 16 + v] = a;
-                    relli[(k * EMAX + cnt) * 16 + v] = w;
-                    ++cnt;
-                }
-            }
-        for (; cnt < EMAX; ++cnt) {
-            rellv[(k * EMAX + cnt) * 16 + v] = 0.f;
-            relli[(k * EMAX + cnt) * 16 + v] = 0;
-        }
-    }
-}
-
-// column-w non-zeros of A_k into LDS (ELL form), every k < 3 (zero for k >= K)
-template <int EMAX>
-__device__ __forceinline__ void build_ell(const float* A, int K, float* ellv, int* elli, int tid) {
-    if (tid < 48) {
-        const int k = tid >> 4, w = tid & 15;
-        int cnt = 0;
-        if (k < K)
-            for (int v = 0; v < 16; ++v) {
-                const float a = A[(k * 16 + v) * 16 + w];
-                if (a != 0.f && cnt < EMAX) {
-                    ellv[(k * EMAX + cnt) * 16 + w] = a;
-                    elli[(k * EMAX + cnt) * 16 + w] = v;
-                    ++cnt;
-                }
-            }
-        for (; cnt < EMAX; ++cnt) {
-            ellv[(k * EMAX + cnt) * 16 + w] = 0.f;
-            elli[(k * EMAX + cnt) * 16 + w] = 0;
-        }
-    }
-}
-
 __device__ __forceinline__ float4 load_x4(const GbParams& p, int n, int ci, int t, int vq) {
     float4 v = *reinterpret_cast<const float4*>(p.x + (((size_t)n * p.Ci + ci) * p.T + t) * 16 + vq * 4);
     if (p.in_scale) {
@@ -124,7 +80,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 
 template <int CIP, int COPAD>
-__global__ __launch_bounds__(256) void gcn_bwd_data_kernel(GbParams p) {
+__global__ __launch_bounds__(256, CIP <= 8 ? 2 : 1) void gcn_bwd_data_kernel(GbParams p) {
     constexpr int KQ = 3 * CIP;
     constexpr int MQT = (KQ + 31) / 32;
     constexpr int KQP = MQT * 32;
@@ -134,6 +90,7 @@ __global__ __launch_bounds__(256) void gcn_bwd_data_kernel(GbParams p) {
     float* Wq = smem;                                // [COPAD][KQP]   W[(k,c),ci] as [c][k*CIP+ci]
     float* dys = Wq + COPAD * KQP;                   // [COPAD][P]     dy tile, later the dres tile
     float* xs = dys + COPAD * P;                     // [CIP][P]       x tile, later Wr^T dres
+    float* cfs = xs + CIP * P;                       // [3][16 rotations][16 joints]
     float* red = dys;                                // [4][3*16*16], aliases dys after the loop
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -152,7 +109,6 @@ __global__ __launch_bounds__(256) void gcn_bwd_data_kernel(GbParams p) {
 
     // rotation coefficients: cf[k][R] = A[k][v = this lane's joint][w = joint of the lane that
     // row_ror:R brings here] (the source lane is found by rotating the lane ids themselves)
-    float cf[3][16];
     unsigned rmask[3] = {0u, 0u, 0u};
     static_for<0, 16>([&](auto rt) {
         constexpr int R = decltype(rt)::value;
@@ -160,7 +116,7 @@ __global__ __launch_bounds__(256) void gcn_bwd_data_kernel(GbParams p) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const float a = (k < p.K) ? p.A[(k * 16 + w16) * 16 + src] : 0.f;
-            cf[k][R] = a;
+            if (tid < 16) cfs[(k * 16 + R) * 16 + w16] = a;
             if (__ballot(a != 0.f) != 0ull) rmask[k] |= 1u << R;
         }
     });
@@ -172,24 +128,62 @@ __global__ __launch_bounds__(256) void gcn_bwd_data_kernel(GbParams p) {
     for (int k = 0; k < 3; ++k) dAk[k] = f32x4{0.f, 0.f, 0.f, 0.f};
     __syncthreads();
 
-    for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+    // global -> registers a tile ahead (raw loads), so HBM latency hides under the MFMA + epilogue
+    // of the tile before; data_bn's scale/shift is applied when the registers go to LDS
+    constexpr int DYN = COPAD * 32 / 256, XN = (CIP * 32 + 255) / 256;
+    float4 dyr[DYN], xr4[XN];
+    auto load_tile = [&](int tile) {
         const int n = tile / p.tiles_per_seq;
         const int t0 = (tile % p.tiles_per_seq) * TT;
-        __syncthreads();
-        for (int f = tid; f < COPAD * 32; f += 256) {
+#pragma unroll
+        for (int i = 0; i < DYN; ++i) {
+            const int f = tid + i * 256;
             const int c = f >> 5, row = (f & 31) >> 2, vq = f & 3;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (c < p.Co && t0 + row < p.T)
                 v = *reinterpret_cast<const float4*>(
                     p.dy + (((size_t)n * p.Co + c) * p.T + t0 + row) * 16 + vq * 4);
-            *reinterpret_cast<float4*>(dys + c * P + row * 16 + vq * 4) = v;
+            dyr[i] = v;
         }
-        for (int f = tid; f < CIP * 32; f += 256) {
+#pragma unroll
+        for (int i = 0; i < XN; ++i) {
+            const int f = tid + i * 256;
             const int ci = f >> 5, row = (f & 31) >> 2, vq = f & 3;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ci < p.Ci && t0 + row < p.T) v = load_x4(p, n, ci, t0 + row, vq);
-            *reinterpret_cast<float4*>(xs + ci * P + row * 16 + vq * 4) = v;
+            if (f < CIP * 32 && ci < p.Ci && t0 + row < p.T)
+                v = *reinterpret_cast<const float4*>(
+                    p.x + (((size_t)n * p.Ci + ci) * p.T + t0 + row) * 16 + vq * 4);
+            xr4[i] = v;
         }
+    };
+
+    if ((int)blockIdx.x < p.ntiles) load_tile(blockIdx.x);
+    for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+        const int n = tile / p.tiles_per_seq;
+        const int t0 = (tile % p.tiles_per_seq) * TT;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < DYN; ++i) {
+            const int f = tid + i * 256;
+            *reinterpret_cast<float4*>(dys + (f >> 5) * P + (f & 31) * 4) = dyr[i];
+        }
+#pragma unroll
+        for (int i = 0; i < XN; ++i) {
+            const int f = tid + i * 256;
+            if (f < CIP * 32) {
+                const int ci = f >> 5, row = (f & 31) >> 2, vq = f & 3;
+                float4 v = xr4[i];
+                if (p.in_scale && ci < p.Ci && t0 + row < p.T) {
+                    const int g = vq * 4 * p.Ci + ci;
+                    v.x = v.x * p.in_scale[g] + p.in_shift[g];
+                    v.y = v.y * p.in_scale[g + p.Ci] + p.in_shift[g + p.Ci];
+                    v.z = v.z * p.in_scale[g + 2 * p.Ci] + p.in_shift[g + 2 * p.Ci];
+                    v.w = v.w * p.in_scale[g + 3 * p.Ci] + p.in_shift[g + 3 * p.Ci];
+                }
+                *reinterpret_cast<float4*>(xs + ci * P + (f & 31) * 4) = v;
+            }
+        }
+        if (tile + (int)gridDim.x < p.ntiles) load_tile(tile + gridDim.x);
         __syncthreads();
 
         // dz = Wq^T . dy : rows q = (k,ci), columns = this wave's 32 positions
@@ -230,7 +224,7 @@ __global__ __launch_bounds__(256) void gcn_bwd_data_kernel(GbParams p) {
             static_for<0, 16>([&](auto rt) {
                 constexpr int R = decltype(rt)::value;
                 if ((rmask[kq] >> R) & 1u) {
-                    const float c = cf[kq][R];
+                    const float c = cfs[(kq * 16 + R) * 16 + w16];
 #pragma unroll
                     for (int m = 0; m < MQT; ++m)
 #pragma unroll
@@ -321,152 +315,228 @@ __global__ __launch_bounds__(256) void gcn_bwd_data_kernel(GbParams p) {
 }
 
 // -------------------------------------------------------------- kernel 2: dW, S, dWr, dbr
-template <int CIP, int COPAD, int EMAX>
-__global__ __launch_bounds__(256) void gcn_bwd_weight_kernel(GbParams p) {
+// dW_k[c][ci] = SUM_p dy[c][p] z_k[ci][p],  z_k[ci,(t,w)] = SUM_v x[ci,t,v] A[k,v,w].
+// Per tile of 8 frames: every thread takes x elements straight from HBM with its lane on the
+// joint axis, forms z_0, z_1, z_2 with DPP row rotations (the column twin of kernel 1's
+// coefficients) and writes them to three LDS images; the dy tile goes to LDS next to them (its
+// per-(c,w) frame sums S stay in registers on the way).  One barrier later the MFMA waves run
+// all three products from one A read per k-step.  Two barriers per tile (four with a residual
+// conv); when fewer than four 32x32 output tiles exist the waves split the position axis.
+__device__ __forceinline__ float load_x1(const GbParams& p, int n, int ci, int t, int v) {
+    float x = p.x[(((size_t)n * p.Ci + ci) * p.T + t) * 16 + v];
+    if (p.in_scale) x = x * p.in_scale[v * p.Ci + ci] + p.in_shift[v * p.Ci + ci];
+    return x;
+}
+
+template <int CIP, int COPAD>
+__global__ __launch_bounds__(256, CIP <= 8 ? 2 : 1) void gcn_bwd_weight_kernel(GbParams p) {
     constexpr int MC = COPAD / 32;                   // c tiles
     constexpr int NCI = (CIP + 31) / 32;             // ci tiles
-    constexpr int CIR = NCI * 32;                    // padded ci rows of the z tile
-    constexpr int NTILE = MC * NCI;                  // output tiles per k (<= 4)
+    constexpr int CIR = NCI * 32;                    // padded ci rows of the z images
+    constexpr int NTILE = MC * NCI;                  // output tiles per k (1, 2 or 4)
+    constexpr int KSPLIT = 4 / NTILE;                // waves sharing one output tile
+    constexpr int SSTEPS = (P / 2) / KSPLIT;         // k-steps per wave
     constexpr int PART = 3 * COPAD * CIR + COPAD * 16 + COPAD * CIR + COPAD;
+    constexpr int CPT = (CIP + 1) / 2;               // z rows per thread
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* dys = smem;                               // [COPAD][PS]
-    float* xs = dys + COPAD * PS;                    // [CIR][PS]
-    float* zk = xs + CIR * PS;                       // [CIR][PS]
-    float* ellv = zk + CIR * PS;
-    int* elli = reinterpret_cast<int*>(ellv + 3 * EMAX * 16);
+    float* zk = dys + COPAD * PS;                    // [3][CIR][PS]; zk[0] doubles as the x tile
+    float* czs = zk + 3 * CIR * PS;                  // [3][16 rotations][16 joints]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l31 = lane & 31, half = lane >> 5;
-    const int mt = wave / NCI, nt = wave % NCI;      // this wave's (c tile, ci tile) when wave < NTILE
+    const int l31 = lane & 31, half = lane >> 5, w16 = lane & 15;
+    const int tile_id = wave % NTILE, ks = wave / NTILE;
+    const int mt = tile_id / NCI, nt = tile_id % NCI;
 
-    build_ell<EMAX>(p.A, p.K, ellv, elli, tid);
-    for (int e = tid; e < CIR * PS; e += 256) { xs[e] = 0.f; zk[e] = 0.f; }
-    __syncthreads();
+    // column coefficients: cz[k][R] = A[k][v = joint of the lane row_ror:R brings][w = own joint]
+    unsigned zmask[3] = {0u, 0u, 0u};
+    static_for<0, 16>([&](auto rt) {
+        constexpr int R = decltype(rt)::value;
+        const int src = __float_as_int(row_ror<R>(__int_as_float(w16)));
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float a = (k < p.K) ? p.A[(k * 16 + src) * 16 + w16] : 0.f;
+            if (tid < 16) czs[(k * 16 + R) * 16 + w16] = a;
+            if (__ballot(a != 0.f) != 0ull) zmask[k] |= 1u << R;
+        }
+    });
+#pragma unroll
+    for (int k = 0; k < 3; ++k) zmask[k] = __builtin_amdgcn_readfirstlane(zmask[k]);
 
-    const int pz = tid & 127;                        // position handled in the z pass
-    const int wz = pz & 15;
+    for (int e = tid; e < 3 * CIR * PS; e += 256) zk[e] = 0.f;
+
     f32x16 accw[3];
     f32x16 accr;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { accw[0][r] = 0.f; accw[1][r] = 0.f; accw[2][r] = 0.f; accr[r] = 0.f; }
-    float Sacc[COPAD * 16 / 256];
-#pragma unroll
-    for (int j = 0; j < COPAD * 16 / 256; ++j) Sacc[j] = 0.f;
-    float brsum = 0.f;                               // thread c < COPAD: SUM dres[c]
+    float4 Sacc = make_float4(0.f, 0.f, 0.f, 0.f);   // thread (c, vq): SUM_{n,t} dy[c][t][4vq..4vq+3]
+    float4 Bacc = make_float4(0.f, 0.f, 0.f, 0.f);   // same for dres
+    const int cdy = tid >> 2, vq = tid & 3;          // this thread's dy row segment
+    const int pz = tid & 127;                        // position handled in the z pass
+    const int tz = pz >> 4;
 
+    // global -> registers for one tile (raw loads; issued a tile ahead so HBM latency hides under
+    // the MFMA phase of the tile before)
+    float xr[CPT];
+    float4 dyr[TT];
+    auto load_tile = [&](int tile) {
+        const int n = tile / p.tiles_per_seq;
+        const int t0 = (tile % p.tiles_per_seq) * TT;
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (cdy < p.Co && t0 + t < p.T)
+                v = *reinterpret_cast<const float4*>(
+                    p.dy + (((size_t)n * p.Co + cdy) * p.T + t0 + t) * 16 + vq * 4);
+            dyr[t] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) {
+            const int ci = (tid >> 7) + 2 * i;
+            float x = 0.f;
+            if (ci < p.Ci && t0 + tz < p.T) x = p.x[(((size_t)n * p.Ci + ci) * p.T + t0 + tz) * 16 + w16];
+            xr[i] = x;
+        }
+    };
+
+    if ((int)blockIdx.x < p.ntiles) load_tile(blockIdx.x);
     for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
         const int n = tile / p.tiles_per_seq;
         const int t0 = (tile % p.tiles_per_seq) * TT;
+        const int next = tile + gridDim.x;
+        __syncthreads();                                  // previous tile's MFMA reads are done
+        if (cdy < COPAD) {
+#pragma unroll
+            for (int t = 0; t < TT; ++t) {
+                const float4 v = dyr[t];
+                Sacc.x += v.x; Sacc.y += v.y; Sacc.z += v.z; Sacc.w += v.w;
+                float* d = dys + cdy * PS + t * 16 + vq * 4;
+                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            }
+        }
+        if (p.in_scale) {
+#pragma unroll
+            for (int i = 0; i < CPT; ++i) {
+                const int ci = (tid >> 7) + 2 * i;
+                if (ci < p.Ci && t0 + tz < p.T)
+                    xr[i] = xr[i] * p.in_scale[w16 * p.Ci + ci] + p.in_shift[w16 * p.Ci + ci];
+            }
+        }
+        {
+            // rotations outside, rows inside: one uniform branch per live (k, rotation) pair
+            float z[3][CPT];
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int i = 0; i < CPT; ++i) z[k][i] = 0.f;
+            static_for<0, 16>([&](auto rt) {
+                constexpr int R = decltype(rt)::value;
+                static_for<0, 3>([&](auto kt) {
+                    constexpr int k = decltype(kt)::value;
+                    if ((zmask[k] >> R) & 1u) {
+                        const float c = czs[(k * 16 + R) * 16 + w16];
+#pragma unroll
+                        for (int i = 0; i < CPT; ++i) z[k][i] = fmaf(c, row_ror<R>(xr[i]), z[k][i]);
+                    }
+                });
+            });
+#pragma unroll
+            for (int i = 0; i < CPT; ++i) {
+                const int ci = (tid >> 7) + 2 * i;
+                if (ci < CIP) {
+                    zk[ci * PS + pz] = z[0][i];
+                    zk[(CIR + ci) * PS + pz] = z[1][i];
+                    zk[(2 * CIR + ci) * PS + pz] = z[2][i];
+                }
+            }
+        }
+        if (!p.dres && next < p.ntiles) load_tile(next);
         __syncthreads();
-        for (int f = tid; f < COPAD * 32; f += 256) {
-            const int c = f >> 5, r4 = f & 31;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (c < p.Co && t0 + (r4 >> 2) < p.T)
-                v = *reinterpret_cast<const float4*>(
-                    p.dy + (((size_t)n * p.Co + c) * p.T + t0 + (r4 >> 2)) * 16 + (r4 & 3) * 4);
-            float* d = dys + c * PS + r4 * 4;
-            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-        }
-        for (int f = tid; f < CIP * 32; f += 256) {
-            const int ci = f >> 5, r4 = f & 31;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ci < p.Ci && t0 + (r4 >> 2) < p.T) v = load_x4(p, n, ci, t0 + (r4 >> 2), r4 & 3);
-            float* d = xs + ci * PS + r4 * 4;
-            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-        }
-        __syncthreads();
-        // S[c,w] += SUM_t dy[c,t,w]
-#pragma unroll
-        for (int j = 0; j < COPAD * 16 / 256; ++j) {
-            const int e = tid + j * 256;
-            const int c = e >> 4, w = e & 15;
-            float s = 0.f;
-#pragma unroll
-            for (int t = 0; t < TT; ++t) s += dys[c * PS + t * 16 + w];
-            Sacc[j] += s;
-        }
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            if (k < p.K) {
-                // z_k[ci][p] = SUM_e A_k[idx_e, w] x[ci][t, idx_e]
-                float a[EMAX];
-                int ix[EMAX];
-#pragma unroll
-                for (int e = 0; e < EMAX; ++e) {
-                    a[e] = ellv[(k * EMAX + e) * 16 + wz];
-                    ix[e] = elli[(k * EMAX + e) * 16 + wz];
-                }
-                for (int ci = tid >> 7; ci < CIP; ci += 2) {
-                    const float* xr = xs + ci * PS + (pz & ~15);
-                    float z = 0.f;
-#pragma unroll
-                    for (int e = 0; e < EMAX; ++e) z = fmaf(a[e], xr[ix[e]], z);
-                    zk[ci * PS + pz] = z;
-                }
-                __syncthreads();
-                if (wave < NTILE) {
-                    const float* ap = dys + (mt * 32 + l31) * PS + half;
-                    const float* bp = zk + (nt * 32 + l31) * PS + half;
-#pragma unroll 8
-                    for (int s = 0; s < P / 2; ++s)
-                        accw[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * s], bp[2 * s], accw[k], 0, 0, 0);
-                }
-                __syncthreads();
+        {
+            const float* ap = dys + (mt * 32 + l31) * PS + half + 2 * ks * SSTEPS;
+            const float* bp = zk + (nt * 32 + l31) * PS + half + 2 * ks * SSTEPS;
+#pragma unroll 4
+            for (int s = 0; s < SSTEPS; ++s) {
+                const float a = ap[2 * s];
+                accw[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp[2 * s], accw[0], 0, 0, 0);
+                accw[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp[CIR * PS + 2 * s], accw[1], 0, 0, 0);
+                accw[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp[2 * CIR * PS + 2 * s], accw[2], 0, 0, 0);
             }
         }
         if (p.dres) {
-            // dWr[c,ci] += SUM_{t',w} dres[c,t',w] x[ci, s*t', w];  dres tile goes into dys
-            const int npos = p.stride == 1 ? 128 : 64;
+            // dWr[c,ci] += SUM_{t',w} dres[c,t',w] x[ci, s*t', w]: dres tile -> dys, x tile -> zk[0]
+            const int nfr = p.stride == 1 ? TT : TT / 2;        // dres frames under this tile
             const int tr0 = t0 / p.stride;
-            for (int f = tid; f < COPAD * (npos / 4); f += 256) {
-                const int c = f / (npos / 4), r4 = f % (npos / 4);
-                const int to = tr0 + (r4 >> 2);
+            float4 drr[TT];
+#pragma unroll
+            for (int t = 0; t < TT; ++t) {
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (c < p.Co && to < p.To)
+                if (t < nfr && cdy < p.Co && tr0 + t < p.To)
                     v = *reinterpret_cast<const float4*>(
-                        p.dres + (((size_t)n * p.Co + c) * p.To + to) * 16 + (r4 & 3) * 4);
-                float* d = dys + c * PS + r4 * 4;
-                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+                        p.dres + (((size_t)n * p.Co + cdy) * p.To + tr0 + t) * 16 + vq * 4);
+                drr[t] = v;
             }
             __syncthreads();
-            if (tid < COPAD) {
-                float s = 0.f;
-                for (int i = 0; i < npos; ++i) s += dys[tid * PS + i];
-                brsum += s;
-            }
-            if (wave < NTILE) {
-                const float* ap = dys + (mt * 32 + l31) * PS + half;
-                const float* bp = xs + (nt * 32 + l31) * PS + half;
-                for (int tl = 0; tl < npos / 16; ++tl) {
+            if (cdy < COPAD) {
 #pragma unroll
-                    for (int v2 = 0; v2 < 8; ++v2)
-                        accr = __builtin_amdgcn_mfma_f32_32x32x2f32(
-                            ap[tl * 16 + 2 * v2], bp[p.stride * tl * 16 + 2 * v2], accr, 0, 0, 0);
+                for (int t = 0; t < TT; ++t) {
+                    const float4 v = drr[t];
+                    Bacc.x += v.x; Bacc.y += v.y; Bacc.z += v.z; Bacc.w += v.w;
+                    float* d = dys + cdy * PS + t * 16 + vq * 4;
+                    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
                 }
+            }
+#pragma unroll
+            for (int i = 0; i < CPT; ++i) {
+                const int ci = (tid >> 7) + 2 * i;
+                if (ci < CIP) zk[ci * PS + pz] = xr[i];
+            }
+            if (next < p.ntiles) load_tile(next);
+            __syncthreads();
+            // frames past nfr of the dres tile are zero; k-steps are (frame tl, joint pair v2)
+            const float* ap = dys + (mt * 32 + l31) * PS + half;
+            const float* bp = zk + (nt * 32 + l31) * PS + half;
+            for (int q = ks * SSTEPS; q < (ks + 1) * SSTEPS; ++q) {
+                const int tl = q >> 3, v2 = q & 7;
+                if (tl < nfr)
+                    accr = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[tl * 16 + 2 * v2],
+                                                                bp[p.stride * tl * 16 + 2 * v2], accr, 0, 0, 0);
             }
         }
     }
 
+    // combine the KSPLIT waves of each output tile through LDS, then write the block partial
     float* part = p.part2 + (size_t)blockIdx.x * PART;
-    if (wave < NTILE) {
+    __syncthreads();
+    float* red = smem;                                   // [4 waves][4 tiles of 16 regs][64 lanes]
 #pragma unroll
-        for (int k = 0; k < 3; ++k)
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[(wave * 64 + k * 16 + r) * 64 + lane] = accw[k][r];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[(wave * 64 + 48 + r) * 64 + lane] = accr[r];
+    __syncthreads();
+    if (ks == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
+                float s = 0.f;
+#pragma unroll
+                for (int j = 0; j < KSPLIT; ++j) s += red[((tile_id + j * NTILE) * 64 + k * 16 + r) * 64 + lane];
                 const int c = mt * 32 + rowmap(r, half);
-                part[(k * COPAD + c) * CIR + nt * 32 + l31] = accw[k][r];
+                if (k < 3) part[(k * COPAD + c) * CIR + nt * 32 + l31] = s;
+                else part[3 * COPAD * CIR + COPAD * 16 + c * CIR + nt * 32 + l31] = s;
             }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int c = mt * 32 + rowmap(r, half);
-            part[3 * COPAD * CIR + COPAD * 16 + c * CIR + nt * 32 + l31] = accr[r];
-        }
-    } else {
-        // tiles nobody owns (NTILE < 4 never leaves gaps: every (mt, nt) < NTILE is owned)
     }
-#pragma unroll
-    for (int j = 0; j < COPAD * 16 / 256; ++j) part[3 * COPAD * CIR + tid + j * 256] = Sacc[j];
-    if (tid < COPAD) part[3 * COPAD * CIR + COPAD * 16 + COPAD * CIR + tid] = brsum;
+    if (cdy < COPAD) {
+        float* ps = part + 3 * COPAD * CIR + cdy * 16 + vq * 4;
+        ps[0] = Sacc.x; ps[1] = Sacc.y; ps[2] = Sacc.z; ps[3] = Sacc.w;
+        float b = (Bacc.x + Bacc.y) + (Bacc.z + Bacc.w);
+        b += __shfl_xor(b, 1, 64);
+        b += __shfl_xor(b, 2, 64);
+        if (vq == 0) part[3 * COPAD * CIR + COPAD * 16 + COPAD * CIR + cdy] = b;
+    }
 }
 
 // ---------------------------------------------------------------------- finalize
@@ -576,8 +646,9 @@ bool gb_geom(int N, int Ci, int Co, int T, int nnz, GbGeom* g) {
     g->emax = nnz <= 4 ? 4 : 16;
     g->cir = g->cip <= 32 ? 32 : 64;
     const int kqp = ((3 * g->cip + 31) / 32) * 32;
-    g->lds1 = ((size_t)g->copad * kqp + (size_t)g->copad * P + (size_t)g->cip * P) * 4;
-    g->lds2 = ((size_t)g->copad * PS + 2 * (size_t)g->cir * PS + 2 * 3 * (size_t)g->emax * 16) * 4;
+    g->lds1 = ((size_t)g->copad * kqp + (size_t)g->copad * P + (size_t)g->cip * P + 768) * 4;
+    g->lds2 = ((size_t)g->copad * PS + 3 * (size_t)g->cir * PS + 768) * 4;
+    if (g->lds2 < 4 * 64 * 64 * 4) g->lds2 = 4 * 64 * 64 * 4;       // the end-of-kernel wave reduction
     const long long ntiles = (long long)N * ((T + TT - 1) / TT);
     auto blocks = [&](size_t lds) {
         int per = (int)((160 * 1024) / lds);
@@ -592,10 +663,10 @@ bool gb_geom(int N, int Ci, int Co, int T, int nnz, GbGeom* g) {
     return g->lds1 <= 160 * 1024 && g->lds2 <= 160 * 1024;
 }
 
-template <int CIP, int COPAD, int EMAX>
+template <int CIP, int COPAD>
 int launch_gb(const GbParams& p, const GbGeom& g, hipStream_t st) {
     auto k1 = gcn_bwd_data_kernel<CIP, COPAD>;
-    auto k2 = gcn_bwd_weight_kernel<CIP, COPAD, EMAX>;
+    auto k2 = gcn_bwd_weight_kernel<CIP, COPAD>;
     hipError_t e = hipSuccess;
     if (g.lds1 > 64 * 1024)
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(k1),
@@ -612,16 +683,15 @@ int launch_gb(const GbParams& p, const GbGeom& g, hipStream_t st) {
     return step::check_launch("step_gcn_bwd");
 }
 
-template <int EMAX>
 int dispatch_gb(const GbParams& p, const GbGeom& g, hipStream_t st) {
     const int key = g.cip * 100 + g.copad;
     switch (key) {
-        case 832: return launch_gb<8, 32, EMAX>(p, g, st);
-        case 864: return launch_gb<8, 64, EMAX>(p, g, st);
-        case 3232: return launch_gb<32, 32, EMAX>(p, g, st);
-        case 3264: return launch_gb<32, 64, EMAX>(p, g, st);
-        case 6432: return launch_gb<64, 32, EMAX>(p, g, st);
-        case 6464: return launch_gb<64, 64, EMAX>(p, g, st);
+        case 832: return launch_gb<8, 32>(p, g, st);
+        case 864: return launch_gb<8, 64>(p, g, st);
+        case 3232: return launch_gb<32, 32>(p, g, st);
+        case 3264: return launch_gb<32, 64>(p, g, st);
+        case 6432: return launch_gb<64, 32>(p, g, st);
+        case 6464: return launch_gb<64, 64>(p, g, st);
     }
     step::set_error("step_gcn_bwd: no kernel for Ci=%d Co=%d", p.Ci, p.Co);
     return STEP_ERR_ARG;
@@ -670,7 +740,7 @@ extern "C" int step_gcn_bwd(const float* dy, const float* dres, const float* x, 
     p.tiles_per_seq = (T + TT - 1) / TT;
     p.ntiles = N * p.tiles_per_seq;
     hipStream_t st = (hipStream_t)stream;
-    int rc = g.emax == 4 ? dispatch_gb<4>(p, g, st) : dispatch_gb<16>(p, g, st);
+    int rc = dispatch_gb(p, g, st);
     if (rc) return rc;
     float* tot1 = p.part2 + (size_t)g.nblk2 * g.part2;
     float* tot2 = tot1 + g.part1;
