@@ -23,6 +23,14 @@ int check_launch(const char* what);
 int wgrad_reduce(const float* slab, const float* dbslab, float* dw, float* db, int Co, int Ci, int Kt,
                  int nsplit, int transposed, hipStream_t st, const char* what);
 
+
+// fp32 sliding-window wgrad (tcn_wgrad_sw.hip): workspace bytes (0 = shape not covered) and the
+// launch; wgrad_sw returns 1 when the shape is not covered or the workspace is too small for it
+size_t wgrad_sw_ws_bytes(int N, int Ci, int Co, int Kt, int stride);
+int wgrad_sw(const float* dout, const float* in, const float* in_scale, const float* in_shift, int in_relu,
+             float* dw, float* db, int N, int Ci, int Co, int Tin, int Tout, int Kt, int stride,
+             int transposed, void* ws, size_t ws_bytes, hipStream_t st);
+
 }  // namespace step
 
 #define STEP_REQUIRE(cond, ...)                         \

@@ -90,6 +90,9 @@ __global__ __launch_bounds__(64 * (MW * NW + NPROD)) void tcn_bf16_kernel(TbPara
     if (wave >= Cfg::NCONS) {
         // ------------------------------------------------------------ staging waves
         const int ptid = tid - 64 * Cfg::NCONS;
+        // the MFMA wave on this SIMD always has an instruction ready and would win every
+        // arbitration; the staging wave issues rarely (it mostly waits on memory) but must not queue
+        __builtin_amdgcn_s_setprio(3);
         float4 sreg[Cfg::SF4];
         // HBM -> registers (raw); the loads stay in flight across the barrier
         auto load_regs = [&](int tile, int g) {

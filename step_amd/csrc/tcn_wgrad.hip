@@ -15,6 +15,7 @@
 // registers over the whole slice; slices are combined by a second, ordered pass
 // (bit-reproducible, no float atomics).
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -342,7 +343,12 @@ extern "C" size_t step_tcn_wgrad_ws_bytes(int N, int Ci, int Co, int Tin, int To
     WgGeom g;
     (void)Tin; (void)Tout;
     if (!wg_geom(N, Ci, Co, Kt, 1, &g)) return 0;
-    return g.ws;                                        // nsplit does not depend on the stride
+    size_t need = g.ws;                                 // nsplit does not depend on the stride
+    for (int s = 1; s <= 2; ++s) {                      // the sliding-window variant, where it applies
+        const size_t sw = step::wgrad_sw_ws_bytes(N, Ci, Co, Kt, s);
+        need = sw > need ? sw : need;
+    }
+    return need;
 }
 
 extern "C" int step_tcn_wgrad(const float* dout, const float* in, const float* in_scale,
@@ -361,6 +367,11 @@ extern "C" int step_tcn_wgrad(const float* dout, const float* in, const float* i
     if (ws_bytes < g.ws) {
         step::set_error("step_tcn_wgrad: workspace %zu < %zu bytes", ws_bytes, g.ws);
         return STEP_ERR_WORKSPACE;
+    }
+    if (!getenv("STEP_WGRAD_OLD")) {
+        const int rc_sw = step::wgrad_sw(dout, in, in_scale, in_shift, in_relu, dw, db, N, Ci, Co, Tin, Tout, Kt,
+                                         stride, transposed, ws, ws_bytes, (hipStream_t)stream);
+        if (rc_sw != 1) return rc_sw;
     }
     WgParams p{};
     p.dout = dout; p.in = in; p.in_scale = in_scale; p.in_shift = in_shift; p.in_relu = in_relu;

@@ -87,6 +87,9 @@ __global__ __launch_bounds__(512) void tcn_wgrad_bf16_kernel(WbParams p) {
     if (wave >= C::NCONS) {
         // ------------------------------------------------------------ staging waves
         const int ptid = tid - 64 * C::NCONS;
+        // the MFMA wave on this SIMD always has an instruction ready and would win every
+        // arbitration; the staging wave issues rarely (it mostly waits on memory) but must not queue
+        __builtin_amdgcn_s_setprio(3);
         float4 dv[C::DN], av[C::AN];
         float dbacc[C::DN];
 #pragma unroll

@@ -1,0 +1,356 @@
+// Weight gradient of the temporal (Kt x 1) convolution, fp32 MFMA, sliding-window form.
+//
+// Same operator and results as tcn_wgrad.hip (weight part of convolution_backward for tcn[2],
+// classifier_stgcn_real_only/net/classifier.py:156-162), arranged like tcn_wgrad_bf16.hip:
+//   G[co][ci][j] = SUM_{n,t,v} dout[n,co,t,v] * a[n,ci,s*t + j - pad, v],  a = relu(bn1(y))
+// GEMM view: M = co, N = (tap j, ci) with the 32 lanes of a column tile on 32 INPUT CHANNELS,
+// K = (n, t, v).  v_mfma_f32_32x32x2_f32: k-step s of a frame pairs joints (s, s + 8), so a
+// lane's eight A (or B) values of one frame are 32 contiguous bytes of the LDS image
+// [channel][frame][16 joints] - two 16-byte reads feed 8 MFMAs per accumulator tile.  The B
+// fragment of (frame t, tap j) depends only on s*t + j: an MFMA wave owns NJ consecutive taps and
+// slides a window along t, so one fragment read serves MW*NJ*8 = 80 MFMAs (tcn_wgrad.hip needs a
+// 4-byte LDS read per MFMA, which is what holds it at 0.73 of the MFMA peak).
+// Block = 4 MFMA waves + 4 staging waves (HBM -> registers -> BN + ReLU -> LDS, two images, the
+// loads of chunk i+2 in flight across the barrier; exact fp32 bias sums on the way).  Slices of
+// the batch are combined by the ordered reduce of tcn_wgrad.hip (bit-reproducible).
+#include "common.h"
+
+namespace {
+
+struct WsParams {
+    const float* dout;
+    const float* in;
+    const float* in_scale;
+    const float* in_shift;
+    float* slab;        // [nsplit][Co][Q]
+    float* dbslab;      // [nsplit][Co]
+    const float* zeros;  // 64 B of zeros in device memory (source of the frames past the end)
+    int in_relu;
+    int N, Ci, Co, Tin, Tout, Kt, pad;
+    int Q, ntb, nqb, nsplit;
+};
+
+template <int MW, int NJ, int STRIDE, int TT>
+struct WsCfg {
+    static constexpr int NCONS = 4, NPROD = 4;
+    static constexpr int NTHR = 64 * (NCONS + NPROD), PTHR = 64 * NPROD;
+    static constexpr int TAPS = NCONS * NJ;                       // taps per block
+    static constexpr int AF = STRIDE * (TT - 1) + TAPS;           // activation frames per chunk
+    // row strides (bytes): an odd number of 16-byte chunks keeps the 16-byte row reads of 32
+    // channels on distinct bank groups
+    static constexpr int CHS = AF * 64 + 16;
+    static constexpr int DS = TT * 64 + 16;
+    static constexpr int D_BYTES = (32 * MW * DS + 1023) / 1024 * 1024;   // whole 1-KiB DMA pieces
+    static constexpr int A_BYTES = (32 * CHS + 1023) / 1024 * 1024;           // whole 1-KiB DMA pieces
+    static constexpr int A_BASE = 2 * D_BYTES;                    // two images each
+    static constexpr int LDS_BYTES = A_BASE + 2 * A_BYTES;
+    static constexpr int D_ITEMS = 32 * MW * TT * 4;              // float4 items of the dout tile
+    static constexpr int A_ITEMS = 32 * AF * 4;
+    static constexpr int DN = D_ITEMS / PTHR;
+    static constexpr int AN = (A_ITEMS + PTHR - 1) / PTHR;
+    static constexpr int NBT = STRIDE * (TT - 1) + NJ;            // B fragments of one chunk (per wave)
+    static_assert(A_BYTES % 16 == 0 && LDS_BYTES <= 160 * 1024, "LDS");
+};
+
+struct frag8 {
+    float4 lo, hi;
+    __device__ __forceinline__ float at(int s) const {
+        switch (s) {
+            case 0: return lo.x; case 1: return lo.y; case 2: return lo.z; case 3: return lo.w;
+            case 4: return hi.x; case 5: return hi.y; case 6: return hi.z; default: return hi.w;
+        }
+    }
+};
+
+template <int MW, int NJ, int STRIDE, int TT>
+__global__ __launch_bounds__(512) void tcn_wgrad_sw_kernel(WsParams p) {
+    using C = WsCfg<MW, NJ, STRIDE, TT>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // blocks that share an XCD (blockIdx % 8) take the q-blocks of the same batch slices
+    int lb = blockIdx.x;
+    if ((gridDim.x & 7) == 0) lb = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const int qb = lb % p.nqb;
+    const int split = lb / p.nqb;
+    const int tb = qb % p.ntb;                        // tap block
+    const int ci0 = (qb / p.ntb) * 32;                // input-channel block
+    const int j0 = tb * C::TAPS;
+    const int n0 = (int)((long long)p.N * split / p.nsplit);
+    const int n1 = (int)((long long)p.N * (split + 1) / p.nsplit);
+    const int nchunks = (p.Tout + TT - 1) / TT;
+    const int total = (n1 - n0) * nchunks;
+
+    if (wave >= C::NCONS) {
+        // ------------------------------------------------------------ staging waves
+        const int ptid = tid - 64 * C::NCONS;
+        const int pwave = wave - C::NCONS;
+
+        // dout tile: a straight copy, so it goes global -> LDS by LDS-DMA (1 KiB per wave
+        // instruction, no VGPRs, no ds_write).  16-byte chunk c of the image is (co = c / CPR,
+        // slot = c % CPR); slot CPR-1 is the row pad (it copies chunk 0 again), frames past the end
+        // of the sequence copy from a zero line.
+        constexpr int CPR = C::DS / 16;                          // chunks per channel row
+        constexpr int DCH = 32 * MW * CPR;                        // chunks of the image
+        constexpr int NPIECE = C::D_BYTES / 1024;
+        constexpr int DPW = (NPIECE + C::NPROD - 1) / C::NPROD;   // DMA instructions per wave
+        auto dma_dout = [&](int item, char* img) {
+            const int n = n0 + item / nchunks;
+            const int t0 = (item % nchunks) * TT;
+            const float* dbase = p.dout + (size_t)n * p.Co * p.Tout * 16;
+#pragma unroll
+            for (int k = 0; k < DPW; ++k) {
+                const int piece = k * C::NPROD + pwave;           // 1 KiB piece of the image
+                const int c = piece * 64 + lane;
+                if (piece < NPIECE) {
+                    const int co = c / CPR, slot = c - co * CPR;
+                    const int w = slot < CPR - 1 ? slot : 0;
+                    const int t = t0 + (w >> 2);
+                    const float* src = (c < DCH && co < p.Co && t < p.Tout)
+                                           ? dbase + ((co * p.Tout + t) * 16 + (w & 3) * 4)
+                                           : p.zeros;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                     (__attribute__((address_space(3))) void*)(img + piece * 1024),
+                                                     16, 0, 0);
+                }
+            }
+        };
+        // exact fp32 bias sums from the landed image (only the block that reports them): TPC
+        // threads share an output channel and split its TT*4 chunks
+        constexpr int TPC = C::PTHR / (32 * MW);
+        float dbacc = 0.f;
+        auto sum_dout = [&](const char* img) {
+            const int co = ptid / TPC, part = ptid % TPC;
+#pragma unroll
+            for (int w = 0; w < (TT * 4 + TPC - 1) / TPC; ++w) {
+                const int ch = part + w * TPC;
+                if (ch < TT * 4) {
+                    const float4 v = *reinterpret_cast<const float4*>(img + co * C::DS + ch * 16);
+                    dbacc += (v.x + v.y) + (v.z + v.w);
+                }
+            }
+        };
+
+        // activation strip: the raw y frames go global -> LDS by DMA as well; tcn[0]/tcn[1] (BN +
+        // ReLU) are applied by the MFMA waves to the fragments they read (a lane of a B fragment is
+        // one input channel, so scale/shift are per-lane constants there), and frames outside the
+        // sequence are zeroed there too.  Chunk c of the image is (channel c / CPA, slot c % CPA);
+        // the per-lane source offsets do not depend on the chunk of the batch: computed once.
+        constexpr int CPA = C::CHS / 16;
+        constexpr int NPA = C::A_BYTES / 1024;
+        constexpr int APW = (NPA + C::NPROD - 1) / C::NPROD;
+        int arel[APW], afr[APW];
+#pragma unroll
+        for (int k = 0; k < APW; ++k) {
+            const int c = (k * C::NPROD + pwave) * 64 + lane;
+            const int cil = c / CPA, slot = c - cil * CPA;
+            const bool data = slot < CPA - 1 && cil < 32 && ci0 + cil < p.Ci;
+            afr[k] = data ? (slot >> 2) : -(1 << 28);
+            arel[k] = data ? (cil * p.Tin + (slot >> 2)) * 16 + (slot & 3) * 4 : 0;
+        }
+        auto dma_act = [&](int item, char* img) {
+            const int n = n0 + item / nchunks;
+            const int t0 = (item % nchunks) * TT;
+            const int row0 = STRIDE * t0 + j0 - p.pad;
+            const float* abase = p.in + ((size_t)n * p.Ci + ci0) * p.Tin * 16 + row0 * 16;
+#pragma unroll
+            for (int k = 0; k < APW; ++k) {
+                const int piece = k * C::NPROD + pwave;
+                if (piece < NPA) {
+                    const float* src = ((unsigned)(row0 + afr[k]) < (unsigned)p.Tin) ? abase + arel[k] : p.zeros;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                     (__attribute__((address_space(3))) void*)(img + piece * 1024),
+                                                     16, 0, 0);
+                }
+            }
+        };
+
+        const bool want_db = (qb == 0) && p.dbslab;
+        auto dbuf = [&](int item) { return smem + (item & 1) * C::D_BYTES; };
+        auto abuf = [&](int item) { return smem + C::A_BASE + (item & 1) * C::A_BYTES; };
+        if (total > 0) { dma_dout(0, dbuf(0)); dma_act(0, abuf(0)); }
+        __syncthreads();                       // (the compiler drains vmcnt before every barrier here)
+        for (int it = 0; it < total; ++it) {
+            // the MFMA waves work on chunk `it`; chunk it+1 is requested into the other images and
+            // has the whole MFMA phase to land
+            if (it + 1 < total) { dma_dout(it + 1, dbuf(it + 1)); dma_act(it + 1, abuf(it + 1)); }
+            if (want_db) sum_dout(dbuf(it));
+            __syncthreads();
+        }
+        if (want_db) {
+            float sdb = dbacc;
+#pragma unroll
+            for (int o = 1; o < TPC; o <<= 1) sdb += __shfl_xor(sdb, o, 64);
+            const int co = ptid / TPC;
+            if (ptid % TPC == 0 && co < p.Co) p.dbslab[(size_t)split * p.Co + co] = sdb;
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------- MFMA waves
+    const int l31 = lane & 31;
+    const int half = lane >> 5;
+    f32x16 acc[MW][NJ];
+#pragma unroll
+    for (int m = 0; m < MW; ++m)
+#pragma unroll
+        for (int i = 0; i < NJ; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][i][r] = 0.f;
+
+    const int aoff = l31 * C::DS + half * 32;                                   // + mt*32*DS + tl*64
+    const int boff = l31 * C::CHS + (wave * NJ) * 64 + half * 32;               // + q*64
+    float bsc = 1.f, bsh = 0.f;                       // tcn[0] of this lane's input channel
+    if (p.in_scale && ci0 + l31 < p.Ci) { bsc = p.in_scale[ci0 + l31]; bsh = p.in_shift[ci0 + l31]; }
+
+    __syncthreads();
+    for (int it = 0; it < total; ++it) {
+        const char* dimg = smem + (it & 1) * C::D_BYTES;
+        const char* aimg = smem + C::A_BASE + (it & 1) * C::A_BYTES;
+        auto read_a = [&](int mt, int tl) -> frag8 {
+            const float4* q = reinterpret_cast<const float4*>(dimg + aoff + mt * 32 * C::DS + tl * 64);
+            return frag8{q[0], q[1]};
+        };
+        auto read_b = [&](int qi) -> frag8 {
+            const float4* q = reinterpret_cast<const float4*>(aimg + boff + qi * 64);
+            return frag8{q[0], q[1]};
+        };
+        // tcn[0] scale/shift + tcn[1] ReLU on a fragment (this lane's channel); frames outside the
+        // sequence are zero (the reference pads after the activation)
+        const int t0c = (it % nchunks) * TT;
+        const int frame0 = STRIDE * t0c + j0 - p.pad + wave * NJ;     // input frame of fragment 0
+        auto activate = [&](frag8& f, int qi) {
+            const bool inside = (unsigned)(frame0 + qi) < (unsigned)p.Tin;      // wave-uniform
+            float* v = reinterpret_cast<float*>(&f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float x = v[e] * bsc + bsh;
+                if (p.in_relu) x = fmaxf(x, 0.f);
+                v[e] = inside ? x : 0.f;
+            }
+        };
+        frag8 a[TT][MW];
+        frag8 b[C::NBT];
+#pragma unroll
+        for (int m = 0; m < MW; ++m) a[0][m] = read_a(m, 0);
+#pragma unroll
+        for (int q = 0; q < NJ && q < C::NBT; ++q) { b[q] = read_b(q); }
+#pragma unroll
+        for (int q = 0; q < NJ && q < C::NBT; ++q) activate(b[q], q);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int tl = 0; tl < TT; ++tl) {
+            if (tl + 1 < TT) {
+#pragma unroll
+                for (int m = 0; m < MW; ++m) a[tl + 1][m] = read_a(m, tl + 1);
+            }
+#pragma unroll
+            for (int s = 0; s < STRIDE; ++s) {
+                const int q = STRIDE * (tl + 1) + NJ - STRIDE + s;
+                if (q < C::NBT) b[q] = read_b(q);
+            }
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+#pragma unroll
+                for (int i = 0; i < NJ; ++i)
+#pragma unroll
+                    for (int m = 0; m < MW; ++m)
+                        acc[m][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tl][m].at(s), b[STRIDE * tl + i].at(s),
+                                                                        acc[m][i], 0, 0, 0);
+            // the fragments read during this frame are first used by the next one
+#pragma unroll
+            for (int s = 0; s < STRIDE; ++s) {
+                const int q = STRIDE * (tl + 1) + NJ - STRIDE + s;
+                if (q < C::NBT) activate(b[q], q);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+    }
+
+    // partial results of this batch slice: column = input channel (lane), row = output channel
+    float* slab = p.slab + (size_t)split * p.Co * p.Q;
+    const int ci = ci0 + l31;
+#pragma unroll
+    for (int i = 0; i < NJ; ++i) {
+        const int j = j0 + wave * NJ + i;
+        if (j < p.Kt && ci < p.Ci) {
+#pragma unroll
+            for (int m = 0; m < MW; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (co < p.Co) slab[(size_t)co * p.Q + ci * p.Kt + j] = acc[m][i][r];
+                }
+        }
+    }
+}
+
+struct WsGeom {
+    int mw, taps, ntb, nqb, nsplit;
+    size_t ws;
+};
+
+bool ws_geom(int N, int Ci, int Co, int Kt, int stride, WsGeom* g) {
+    if (Kt != 75 || N < 1 || (Ci != 32 && Ci != 64) || Ci != Co || (stride != 1 && stride != 2)) return false;
+    g->mw = Co / 32;
+    g->taps = 20;
+    g->ntb = step::ceil_div(Kt, g->taps);
+    g->nqb = g->ntb * (Ci / 32);
+    int ns = 256 / g->nqb;                     // one block per CU
+    ns = ns < 1 ? 1 : ns;
+    g->nsplit = ns < N ? ns : N;
+    g->ws = ((size_t)g->nsplit * Co * Ci * Kt + (size_t)g->nsplit * Co + 16) * 4;   // + a zero line
+    return true;
+}
+
+template <int MW, int NJ, int STRIDE, int TT>
+int launch_ws(const WsParams& p, hipStream_t st) {
+    using C = WsCfg<MW, NJ, STRIDE, TT>;
+    auto kern = tcn_wgrad_sw_kernel<MW, NJ, STRIDE, TT>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+    if (e != hipSuccess) {
+        step::set_error("step_tcn_wgrad: hipFuncSetAttribute(%d): %s", C::LDS_BYTES, hipGetErrorString(e));
+        return STEP_ERR_LAUNCH;
+    }
+    hipLaunchKernelGGL(kern, dim3(p.nqb * p.nsplit), dim3(C::NTHR), C::LDS_BYTES, st, p);
+    return step::check_launch("step_tcn_wgrad(sliding)");
+}
+
+}  // namespace
+
+size_t step::wgrad_sw_ws_bytes(int N, int Ci, int Co, int Kt, int stride) {
+    WsGeom g;
+    return ws_geom(N, Ci, Co, Kt, stride, &g) ? g.ws : 0;
+}
+
+// returns 1 when this variant does not cover the shape (the caller runs tcn_wgrad.hip's kernel)
+int step::wgrad_sw(const float* dout, const float* in, const float* in_scale, const float* in_shift,
+                   int in_relu, float* dw, float* db, int N, int Ci, int Co, int Tin, int Tout, int Kt,
+                   int stride, int transposed, void* ws, size_t ws_bytes, hipStream_t st) {
+    WsGeom g;
+    if (!ws_geom(N, Ci, Co, Kt, stride, &g) || ws_bytes < g.ws) return 1;
+    WsParams p{};
+    p.dout = dout; p.in = in; p.in_scale = in_scale; p.in_shift = in_shift; p.in_relu = in_relu;
+    p.slab = (float*)ws;
+    p.dbslab = p.slab + (size_t)g.nsplit * Co * Ci * Kt;
+    float* zl = p.dbslab + (size_t)g.nsplit * Co;
+    if (hipMemsetAsync(zl, 0, 64, st) != hipSuccess) {
+        step::set_error("step_tcn_wgrad: hipMemsetAsync failed");
+        return STEP_ERR_LAUNCH;
+    }
+    p.zeros = zl;
+    p.N = N; p.Ci = Ci; p.Co = Co; p.Tin = Tin; p.Tout = Tout; p.Kt = Kt;
+    p.pad = (Kt - 1) / 2;
+    p.Q = Ci * Kt; p.ntb = g.ntb; p.nqb = g.nqb; p.nsplit = g.nsplit;
+    int rc;
+    if (g.mw == 1) rc = stride == 1 ? launch_ws<1, 5, 1, 6>(p, st) : launch_ws<1, 5, 2, 4>(p, st);
+    else rc = stride == 1 ? launch_ws<2, 5, 1, 6>(p, st) : launch_ws<2, 5, 2, 4>(p, st);
+    if (rc) return rc;
+    return step::wgrad_reduce(p.slab, p.dbslab, dw, db, Co, Ci, Kt, g.nsplit, transposed, st,
+                              "step_tcn_wgrad(sliding, reduce)");
+}
