@@ -229,7 +229,7 @@ def main():
                 "flops_per_launch": tcn_flops(args.batch, dom["C"], (args.frames - 1) // 2 + 1
                                               if dom["kernel"].endswith(("b1", "b2")) else args.frames)}
     cpu = None
-    if rank == 0 and not args.no_cpu:
+    if rank == 0 and world == 1 and not args.no_cpu:       # CPU baseline: rank 0 at N=1 only
         cpu = cpu_baseline(args.frames)
 
     if rank == 0:
@@ -251,6 +251,7 @@ def main():
         }
         print(json.dumps(line))
     if world > 1:
+        dist.barrier()                                     # rank 0's extra measurements are done
         dist.destroy_process_group()
 
 
