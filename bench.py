@@ -27,6 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense (nominal clock)
 
 
@@ -98,6 +99,64 @@ def time_kernels(n, t, device, reps=3, bf16=False):
                         "tflops": round(fl / ms / 1e9, 2),
                         "frac": round(fl / ms / 1e9 / peak, 4)})
         del y, du
+    return out
+
+
+def time_hbm_kernels(n, t, device, reps=3):
+    """HIP-event timing of the HBM-bound stages of each block (graph conv fwd / bwd, BN statistics,
+    BN+residual+ReLU apply, BN backward), with their algorithmic bytes (each tensor read or written
+    once; 4 B per element) against the 8 TB/s HBM3E peak."""
+    from step_amd import _lib, ops
+    from step_amd.net.utils.graph import Graph
+    out = []
+    A = torch.tensor(Graph(strategy="spatial").A, dtype=torch.float32).to(device)
+    nnz = ops.a_nnz_max(A)
+    g = torch.Generator().manual_seed(3)
+    for bi, (ci, co, tt, st, resconv) in enumerate([(3, 32, t, 1, True), (32, 64, t, 2, True),
+                                                    (64, 64, (t - 1) // 2 + 1, 1, False)]):
+        to = (tt - 1) // st + 1
+        x = torch.randn(n, ci, tt, 16, generator=g).to(device)
+        w = (torch.randn(3 * co, ci, generator=g) * 0.1).to(device)
+        b = torch.zeros(3 * co, device=device)
+        y = torch.empty(n, co, tt, 16, device=device)
+        dy = torch.randn(n, co, tt, 16, generator=g).to(device)
+        rw = (torch.randn(co, ci, generator=g) * 0.1).to(device) if resconv else None
+        rb = torch.zeros(co, device=device) if resconv else None
+        r = torch.empty(n, co, to, 16, device=device) if resconv else None
+        dr = torch.randn(n, co, to, 16, generator=g).to(device) if resconv else None
+        dx, dw, db, dA = torch.empty_like(x), torch.empty_like(w), torch.empty_like(b), torch.empty_like(A)
+        drw = torch.empty_like(rw) if resconv else None
+        drb = torch.empty(co, device=device) if resconv else None
+        nb = _lib.query("step_gcn_bwd_ws_bytes", n, ci, co, 3, tt)
+        ws = torch.empty(nb, dtype=torch.uint8, device=device)
+        bnw, bnb = torch.ones(co, device=device), torch.zeros(co, device=device)
+        rm, rv = torch.zeros(co, device=device), torch.ones(co, device=device)
+        mean, invstd, sc, sh = ops.bn_train_prepare(dy, 0, bnw, bnb, rm, rv)
+        rn = r.numel() if resconv else 0
+        calls = {
+            "gcn_fwd": (lambda: _lib.call("step_gcn_fwd", x, None, None, w, b, 0, A, nnz, y, rw, rb, 0, r,
+                                          n, ci, co, 3, tt, st), x.numel() + y.numel() + rn),
+            "gcn_bwd": (lambda: _lib.call("step_gcn_bwd", dy, dr, x, None, None, w, b, 0, A, nnz, rw, 0, dx, dw, db,
+                                          dA, drw, drb, n, ci, co, 3, tt, st, ws, nb),
+                        2 * (x.numel() + dy.numel() + rn) + dx.numel()),
+            "bn_stats": (lambda: ops.bn_train_prepare(dy, 0, bnw, bnb, rm, rv), dy.numel()),
+            "bn_res_relu": (lambda: ops.affine_act(dy, sc, sh, None, None, None, True, 0), 2 * dy.numel()),
+            "bn_bwd": (lambda: ops.bn_backward(dy, y, None, sc, sh, 2, mean, invstd, bnw, True, 0), 5 * dy.numel()),
+        }
+        for name, (fn, nel) in calls.items():
+            fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / reps
+            gbs = 4.0 * nel / ms / 1e6
+            out.append({"kernel": "%s_b%d" % (name, bi), "bound": "hbm", "ms": round(ms, 3),
+                        "gbs": round(gbs, 1), "frac": round(gbs / PEAK_HBM_GBS, 4)})
+        del x, y, dy, dx, r, dr, ws
     return out
 
 
@@ -216,6 +275,8 @@ def main():
         torch.cuda.empty_cache()
         kernels = time_kernels(args.batch, args.frames, device, bf16=(args.mfma == "bf16"))
         dom = max(kernels, key=lambda k: k["ms"])
+        torch.cuda.empty_cache()
+        kernels = kernels + time_hbm_kernels(args.batch, args.frames, device)
         traffic = None
         try:    # HBM bytes per launch from the committed PMC passes (same shape, N=4096 only)
             with open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")) as fh:
