@@ -277,3 +277,25 @@ def test_graph_conv_modules_standalone():
         assert_close(y, ref, 1e-4, "y")
         y.sum().backward()
         assert xg.grad is not None and mod.conv.weight.grad is not None
+
+
+def test_batched_prediction_and_feature_export():
+    """processor.py:457-473 / :489-515 in large batches == the reference's batch-1 loop
+    (its outputs on the shipped 60-gait fixture are in classifier_real_only_eval.npz)."""
+    import numpy as np
+    from step_amd import export
+    from step_amd.net.classifier import Classifier
+    m = _load(Classifier(3, 4, {"strategy": "spatial"}), ckpt("ckpt_classifier_real_only_epoch395")).train()
+    d = sub(load_npz("classifier_real_only_eval"), "")
+    x = d["h5_x"]                                                   # (N, 3, T, 16, 1)
+    N, _, T, V, _ = x.shape
+    raw = x[..., 0].permute(0, 2, 3, 1).reshape(N, T, V * 3).numpy()    # the loader's (N, T, 48)
+    labels, out = export.generate_predictions(m, raw, 4, 16, 3, batch=25)
+    assert m.training                                               # mode restored
+    assert_close(torch.tensor(out), d["h5_probs"], 1e-4, "batched probs")
+    assert np.array_equal(labels, d["h5_probs"].argmax(1).numpy().astype(np.float64))
+    feats, by_key = export.extract_features(m, raw, 16, 3, keys=["gait%03d" % i for i in range(N)], batch=32)
+    assert_close(torch.tensor(feats), d["h5_feat"], 1e-4, "batched features")
+    assert feats.shape == (N, 64) and len(by_key) == N and by_key["gait007"].shape == (64,)
+    one, _ = export.generate_predictions(m, raw[:3], 4, 16, 3, batch=1)    # the reference's own batching
+    assert np.array_equal(one, labels[:3])
