@@ -176,8 +176,8 @@ int step_tcn_wgrad(const float* dout, const float* in, const float* in_scale,
 
 /* bf16-operand twin of step_tcn_wgrad (dout and the recomputed activation rounded to bf16 on their
  * way into the MFMA, fp32 accumulation; db stays an exact fp32 sum).  Built for Kt = 75, square
- * 32- or 64-channel convs, stride 1 (and stride 2 at 64 channels); the ws_bytes helper returns 0
- * for anything else and the caller keeps step_tcn_wgrad.  Writes the Conv2d layout (Co,Ci,Kt). */
+ * 32- or 64-channel convs, stride 1 or 2; the ws_bytes helper returns 0 for anything else and the
+ * caller keeps step_tcn_wgrad.  Writes the Conv2d layout (Co,Ci,Kt).                          */
 size_t step_tcn_wgrad_bf16_ws_bytes(int N, int Ci, int Co, int Tin, int Tout, int Kt, int stride);
 int step_tcn_wgrad_bf16(const float* dout, const float* in, const float* in_scale,
                         const float* in_shift, int in_relu, float* dw, float* db,

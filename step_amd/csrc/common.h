@@ -29,7 +29,7 @@ int wgrad_reduce(const float* slab, const float* dbslab, float* dw, float* db, i
 size_t wgrad_sw_ws_bytes(int N, int Ci, int Co, int Kt, int stride);
 int wgrad_sw(const float* dout, const float* in, const float* in_scale, const float* in_shift, int in_relu,
              float* dw, float* db, int N, int Ci, int Co, int Tin, int Tout, int Kt, int stride,
-             int transposed, void* ws, size_t ws_bytes, hipStream_t st);
+             int transposed, void* ws, size_t ws_bytes, hipStream_t st, int bf16 = 0);
 
 }  // namespace step
 

@@ -52,6 +52,9 @@ struct WsCfg {
     static_assert(A_BYTES % 16 == 0 && LDS_BYTES <= 160 * 1024, "LDS");
 };
 
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+
 struct frag8 {
     float4 lo, hi;
     __device__ __forceinline__ float at(int s) const {
@@ -62,7 +65,12 @@ struct frag8 {
     }
 };
 
-template <int MW, int NJ, int STRIDE, int TT>
+__device__ __forceinline__ bf16x8 to_bf16(const frag8& f) {
+    const f32x8 v = {f.lo.x, f.lo.y, f.lo.z, f.lo.w, f.hi.x, f.hi.y, f.hi.z, f.hi.w};
+    return __builtin_convertvector(v, bf16x8);
+}
+
+template <int MW, int NJ, int STRIDE, int TT, bool BF16>
 __global__ __launch_bounds__(512) void tcn_wgrad_sw_kernel(WsParams p) {
     using C = WsCfg<MW, NJ, STRIDE, TT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -252,14 +260,29 @@ __global__ __launch_bounds__(512) void tcn_wgrad_sw_kernel(WsParams p) {
                 const int q = STRIDE * (tl + 1) + NJ - STRIDE + s;
                 if (q < C::NBT) b[q] = read_b(q);
             }
+            if constexpr (BF16) {
+                // bf16 operands: a lane's eight joints of a frame are one v_mfma_f32_32x32x16_bf16
+                // fragment (k = 8*half + e), rounded here, in registers
+                bf16x8 ab[MW], bb[NJ];
 #pragma unroll
-            for (int s = 0; s < 8; ++s)
+                for (int m = 0; m < MW; ++m) ab[m] = to_bf16(a[tl][m]);
+#pragma unroll
+                for (int i = 0; i < NJ; ++i) bb[i] = to_bf16(b[STRIDE * tl + i]);
 #pragma unroll
                 for (int i = 0; i < NJ; ++i)
 #pragma unroll
                     for (int m = 0; m < MW; ++m)
-                        acc[m][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tl][m].at(s), b[STRIDE * tl + i].at(s),
-                                                                        acc[m][i], 0, 0, 0);
+                        acc[m][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab[m], bb[i], acc[m][i], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int s = 0; s < 8; ++s)
+#pragma unroll
+                    for (int i = 0; i < NJ; ++i)
+#pragma unroll
+                        for (int m = 0; m < MW; ++m)
+                            acc[m][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tl][m].at(s), b[STRIDE * tl + i].at(s),
+                                                                            acc[m][i], 0, 0, 0);
+            }
             // the fragments read during this frame are first used by the next one
 #pragma unroll
             for (int s = 0; s < STRIDE; ++s) {
@@ -307,10 +330,10 @@ bool ws_geom(int N, int Ci, int Co, int Kt, int stride, WsGeom* g) {
     return true;
 }
 
-template <int MW, int NJ, int STRIDE, int TT>
+template <int MW, int NJ, int STRIDE, int TT, bool BF16>
 int launch_ws(const WsParams& p, hipStream_t st) {
     using C = WsCfg<MW, NJ, STRIDE, TT>;
-    auto kern = tcn_wgrad_sw_kernel<MW, NJ, STRIDE, TT>;
+    auto kern = tcn_wgrad_sw_kernel<MW, NJ, STRIDE, TT, BF16>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
     if (e != hipSuccess) {
@@ -331,7 +354,7 @@ size_t step::wgrad_sw_ws_bytes(int N, int Ci, int Co, int Kt, int stride) {
 // returns 1 when this variant does not cover the shape (the caller runs tcn_wgrad.hip's kernel)
 int step::wgrad_sw(const float* dout, const float* in, const float* in_scale, const float* in_shift,
                    int in_relu, float* dw, float* db, int N, int Ci, int Co, int Tin, int Tout, int Kt,
-                   int stride, int transposed, void* ws, size_t ws_bytes, hipStream_t st) {
+                   int stride, int transposed, void* ws, size_t ws_bytes, hipStream_t st, int bf16) {
     WsGeom g;
     if (!ws_geom(N, Ci, Co, Kt, stride, &g) || ws_bytes < g.ws) return 1;
     WsParams p{};
@@ -348,8 +371,13 @@ int step::wgrad_sw(const float* dout, const float* in, const float* in_scale, co
     p.pad = (Kt - 1) / 2;
     p.Q = Ci * Kt; p.ntb = g.ntb; p.nqb = g.nqb; p.nsplit = g.nsplit;
     int rc;
-    if (g.mw == 1) rc = stride == 1 ? launch_ws<1, 5, 1, 6>(p, st) : launch_ws<1, 5, 2, 4>(p, st);
-    else rc = stride == 1 ? launch_ws<2, 5, 1, 6>(p, st) : launch_ws<2, 5, 2, 4>(p, st);
+    if (bf16) {
+        if (g.mw == 1) rc = stride == 1 ? launch_ws<1, 5, 1, 6, true>(p, st) : launch_ws<1, 5, 2, 4, true>(p, st);
+        else rc = stride == 1 ? launch_ws<2, 5, 1, 6, true>(p, st) : launch_ws<2, 5, 2, 4, true>(p, st);
+    } else {
+        if (g.mw == 1) rc = stride == 1 ? launch_ws<1, 5, 1, 6, false>(p, st) : launch_ws<1, 5, 2, 4, false>(p, st);
+        else rc = stride == 1 ? launch_ws<2, 5, 1, 6, false>(p, st) : launch_ws<2, 5, 2, 4, false>(p, st);
+    }
     if (rc) return rc;
     return step::wgrad_reduce(p.slab, p.dbslab, dw, db, Co, Ci, Kt, g.nsplit, transposed, st,
                               "step_tcn_wgrad(sliding, reduce)");

@@ -82,7 +82,7 @@ def test_tcn_bf16_dgrad(C, stride, T, N):
 
 @pytest.mark.parametrize("C,stride,T,N", [(64, 1, 33, 2), (64, 1, 16, 5), (32, 1, 50, 3), (64, 2, 41, 2),
                                           (64, 2, 40, 3), (64, 1, 240, 1), (32, 1, 240, 2), (64, 2, 240, 1),
-                                          (64, 1, 7, 300)])
+                                          (64, 1, 7, 300), (32, 2, 21, 2)])
 def test_tcn_bf16_wgrad(C, stride, T, N):
     from step_amd import ops
     Kt = 75
@@ -117,7 +117,6 @@ def test_tcn_bf16_unsupported_shapes_say_so():
     assert not ops.tcn_bf16_supported(64, 64, 75, 1, 1)
     assert not ops.tcn_wgrad_bf16_supported(3, 3, 75, 1)
     assert not ops.tcn_wgrad_bf16_supported(64, 64, 9, 1)
-    assert not ops.tcn_wgrad_bf16_supported(32, 32, 75, 2)
 
 
 # ----------------------------------------------------------------------- whole models, bf16 MFMA
