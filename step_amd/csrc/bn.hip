@@ -112,9 +112,17 @@ __global__ void bn_sum_chunks_kernel(const double* __restrict__ part, double* __
                                      int G, int nchunks) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= 2 * G) return;
-    double s = 0.0;
-    for (int k = 0; k < nchunks; ++k) s += part[(size_t)k * G * 2 + e];
-    tot[e] = s;
+    // four independent chains (the loads are latency-bound), combined in a fixed order
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int k = 0;
+    for (; k + 3 < nchunks; k += 4) {
+        s0 += part[(size_t)k * G * 2 + e];
+        s1 += part[(size_t)(k + 1) * G * 2 + e];
+        s2 += part[(size_t)(k + 2) * G * 2 + e];
+        s3 += part[(size_t)(k + 3) * G * 2 + e];
+    }
+    for (; k < nchunks; ++k) s0 += part[(size_t)k * G * 2 + e];
+    tot[e] = (s0 + s1) + (s2 + s3);
 }
 
 __global__ void bn_train_finalize_kernel(const double* __restrict__ tot, const float* __restrict__ gamma,

@@ -79,18 +79,21 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
-template <int CIP, int COPAD>
+template <int CIP, int COPAD, bool RES>
 __global__ __launch_bounds__(256, CIP <= 8 ? 2 : 1) void gcn_bwd_data_kernel(GbParams p) {
     constexpr int KQ = 3 * CIP;
     constexpr int MQT = (KQ + 31) / 32;
     constexpr int KQP = MQT * 32;
     constexpr int MCI = (CIP + 31) / 32;            // ci tiles of the residual product
+    constexpr int CIRP = MCI * 32;
     constexpr int NDX = CIP >= 32 ? (CIP / 32) * 16 : 4;   // dx registers per lane
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Wq = smem;                                // [COPAD][KQP]   W[(k,c),ci] as [c][k*CIP+ci]
     float* dys = Wq + COPAD * KQP;                   // [COPAD][P]     dy tile, later the dres tile
     float* xs = dys + COPAD * P;                     // [CIP][P]       x tile, later Wr^T dres
     float* cfs = xs + CIP * P;                       // [3][16 rotations][16 joints]
+    float* Wrt = cfs + 768;                          // [COPAD][CIRP]  residual conv weight (RES)
+    float* drs = Wrt + COPAD * CIRP;                 // [COPAD][DW]    dres tile (RES), DW = 128 / stride
     float* red = dys;                                // [4][3*16*16], aliases dys after the loop
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -105,6 +108,17 @@ __global__ __launch_bounds__(256, CIP <= 8 ? 2 : 1) void gcn_bwd_data_kernel(GbP
             v = p.w_transposed ? p.w[(size_t)ci * (p.K * p.Co) + k * p.Co + c]
                                : p.w[((size_t)k * p.Co + c) * p.Ci + ci];
         Wq[e] = v;
+    }
+
+    const int DW = p.stride == 1 ? P : P / 2;        // dres frames under a tile: 8 or 4
+    if (RES) {
+        for (int e = tid; e < COPAD * CIRP; e += 256) {
+            const int ci = e % CIRP, c = e / CIRP;
+            float v = 0.f;
+            if (c < p.Co && ci < p.Ci)
+                v = p.res_transposed ? p.res_w[(size_t)ci * p.Co + c] : p.res_w[(size_t)c * p.Ci + ci];
+            Wrt[e] = v;
+        }
     }
 
     // rotation coefficients: cf[k][R] = A[k][v = this lane's joint][w = joint of the lane that
@@ -131,10 +145,26 @@ __global__ __launch_bounds__(256, CIP <= 8 ? 2 : 1) void gcn_bwd_data_kernel(GbP
     // global -> registers a tile ahead (raw loads), so HBM latency hides under the MFMA + epilogue
     // of the tile before; data_bn's scale/shift is applied when the registers go to LDS
     constexpr int DYN = COPAD * 32 / 256, XN = (CIP * 32 + 255) / 256;
-    float4 dyr[DYN], xr4[XN];
+    constexpr int DRN = RES ? DYN : 1;
+    float4 dyr[DYN], xr4[XN], drr[DRN];
     auto load_tile = [&](int tile) {
         const int n = tile / p.tiles_per_seq;
         const int t0 = (tile % p.tiles_per_seq) * TT;
+        if (RES) {
+            const int q4 = DW / 4;                   // float4 per channel row of the dres tile
+            const int tr0 = t0 / p.stride;
+#pragma unroll
+            for (int i = 0; i < DRN; ++i) {
+                const int f = tid + i * 256;
+                const int c = f / q4, r4 = f - c * q4;
+                const int to = tr0 + (r4 >> 2);
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (f < COPAD * q4 && c < p.Co && to < p.To)
+                    v = *reinterpret_cast<const float4*>(
+                        p.dres + (((size_t)n * p.Co + c) * p.To + to) * 16 + (r4 & 3) * 4);
+                drr[i] = v;
+            }
+        }
 #pragma unroll
         for (int i = 0; i < DYN; ++i) {
             const int f = tid + i * 256;
@@ -166,6 +196,13 @@ __global__ __launch_bounds__(256, CIP <= 8 ? 2 : 1) void gcn_bwd_data_kernel(GbP
         for (int i = 0; i < DYN; ++i) {
             const int f = tid + i * 256;
             *reinterpret_cast<float4*>(dys + (f >> 5) * P + (f & 31) * 4) = dyr[i];
+        }
+        if (RES) {
+#pragma unroll
+            for (int i = 0; i < DRN; ++i) {
+                const int f = tid + i * 256;
+                if (f < COPAD * (DW / 4)) *reinterpret_cast<float4*>(drs + f * 4) = drr[i];
+            }
         }
 #pragma unroll
         for (int i = 0; i < XN; ++i) {
@@ -239,58 +276,28 @@ __global__ __launch_bounds__(256, CIP <= 8 ? 2 : 1) void gcn_bwd_data_kernel(GbP
             });
         });
 
-        // residual branch: dx[ci, s*t', w] += SUM_c Wr[c,ci] dres[c, t', w]   (through LDS: for
-        // stride 2 the output columns of this product belong to other waves' frames)
-        if (p.dres) {
-            __syncthreads();                                          // dys and xs are free now
-            const int npos = p.stride == 1 ? 128 : 64;
-            const int tr0 = t0 / p.stride;
-            for (int f = tid; f < COPAD * (npos / 4); f += 256) {
-                const int c = f / (npos / 4);
-                const int r4 = f % (npos / 4);
-                const int to = tr0 + (r4 >> 2);
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (c < p.Co && to < p.To)
-                    v = *reinterpret_cast<const float4*>(
-                        p.dres + (((size_t)n * p.Co + c) * p.To + to) * 16 + (r4 & 3) * 4);
-                *reinterpret_cast<float4*>(dys + c * P + r4 * 4) = v;
-            }
-            __syncthreads();
-            if (wave * 32 < npos) {
-                f32x16 ar[MCI];
+        // residual branch: dx[ci, s*t', w] += SUM_c Wr[c,ci] dres[c, t', w].  Its product has the
+        // layout of dz (row = ci in the register, column = (t, w) on the lane), so it is one more
+        // MFMA chain on the same columns and adds straight into dx; at stride 2 only the even
+        // frames of the tile receive a contribution.
+        if (RES) {
+            f32x16 ar[MCI];
 #pragma unroll
-                for (int m = 0; m < MCI; ++m)
+            for (int m = 0; m < MCI; ++m)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) ar[m][r] = 0.f;
-                const float* bp = dys + half * P + wave * 32 + l31;
-                for (int s = 0; s < COPAD / 2; ++s) {
-                    const int c = 2 * s + half;
-                    const float bv = bp[s * 2 * P];
-#pragma unroll
-                    for (int m = 0; m < MCI; ++m) {
-                        const int ci = m * 32 + l31;
-                        float a = 0.f;
-                        if (c < p.Co && ci < p.Ci)
-                            a = p.res_transposed ? p.res_w[(size_t)ci * p.Co + c] : p.res_w[(size_t)c * p.Ci + ci];
-                        ar[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, ar[m], 0, 0, 0);
-                    }
-                }
-#pragma unroll
-                for (int m = 0; m < MCI; ++m)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int ci = m * 32 + rowmap(r, half);
-                        if (ci < CIP) xs[ci * P + wave * 32 + l31] = ar[m][r];
-                    }
-            }
-            __syncthreads();
+                for (int r = 0; r < 16; ++r) ar[m][r] = 0.f;
             const bool mine = p.stride == 1 || (trow & 1) == 0;
             const int col = p.stride == 1 ? trow * 16 + w16 : (trow >> 1) * 16 + w16;
+            const float* bp = drs + half * DW + col;
+            const float* ap = Wrt + half * CIRP + l31;
+            for (int s = 0; s < COPAD / 2; ++s) {
+                const float bv = mine ? bp[s * 2 * DW] : 0.f;
 #pragma unroll
-            for (int i = 0; i < NDX; ++i) {
-                const int ci = CIP >= 32 ? (i / 16) * 32 + rowmap(i & 15, half) : i + 4 * half;
-                if (mine) dxr[i] += xs[ci * P + col];
+                for (int m = 0; m < MCI; ++m)
+                    ar[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[s * 2 * CIRP + m * 32], bv, ar[m], 0, 0, 0);
             }
+#pragma unroll
+            for (int i = 0; i < NDX; ++i) dxr[i] += CIP >= 32 ? ar[i / 16][i & 15] : ar[0][i];
         }
         if (p.dx && t0 + trow < p.T) {
 #pragma unroll
@@ -663,9 +670,9 @@ bool gb_geom(int N, int Ci, int Co, int T, int nnz, GbGeom* g) {
     return g->lds1 <= 160 * 1024 && g->lds2 <= 160 * 1024;
 }
 
-template <int CIP, int COPAD>
+template <int CIP, int COPAD, bool RES>
 int launch_gb(const GbParams& p, const GbGeom& g, hipStream_t st) {
-    auto k1 = gcn_bwd_data_kernel<CIP, COPAD>;
+    auto k1 = gcn_bwd_data_kernel<CIP, COPAD, RES>;
     auto k2 = gcn_bwd_weight_kernel<CIP, COPAD>;
     hipError_t e = hipSuccess;
     if (g.lds1 > 64 * 1024)
@@ -686,12 +693,12 @@ int launch_gb(const GbParams& p, const GbGeom& g, hipStream_t st) {
 int dispatch_gb(const GbParams& p, const GbGeom& g, hipStream_t st) {
     const int key = g.cip * 100 + g.copad;
     switch (key) {
-        case 832: return launch_gb<8, 32>(p, g, st);
-        case 864: return launch_gb<8, 64>(p, g, st);
-        case 3232: return launch_gb<32, 32>(p, g, st);
-        case 3264: return launch_gb<32, 64>(p, g, st);
-        case 6432: return launch_gb<64, 32>(p, g, st);
-        case 6464: return launch_gb<64, 64>(p, g, st);
+        case 832: return p.dres ? launch_gb<8, 32, true>(p, g, st) : launch_gb<8, 32, false>(p, g, st);
+        case 864: return p.dres ? launch_gb<8, 64, true>(p, g, st) : launch_gb<8, 64, false>(p, g, st);
+        case 3232: return p.dres ? launch_gb<32, 32, true>(p, g, st) : launch_gb<32, 32, false>(p, g, st);
+        case 3264: return p.dres ? launch_gb<32, 64, true>(p, g, st) : launch_gb<32, 64, false>(p, g, st);
+        case 6432: return p.dres ? launch_gb<64, 32, true>(p, g, st) : launch_gb<64, 32, false>(p, g, st);
+        case 6464: return p.dres ? launch_gb<64, 64, true>(p, g, st) : launch_gb<64, 64, false>(p, g, st);
     }
     step::set_error("step_gcn_bwd: no kernel for Ci=%d Co=%d", p.Ci, p.Co);
     return STEP_ERR_ARG;
@@ -730,11 +737,23 @@ extern "C" int step_gcn_bwd(const float* dy, const float* dres, const float* x, 
         step::set_error("step_gcn_bwd: workspace %zu < %zu bytes", ws_bytes, need);
         return STEP_ERR_WORKSPACE;
     }
+    const int nblk1_ws = g.nblk1;                    // rows the workspace was sized for
+    if (dres) {
+        // the residual product keeps Wr and the dres tile in LDS too: fewer blocks per CU, never more
+        const int cirp = g.cip <= 32 ? 32 : 64;
+        g.lds1 += ((size_t)g.copad * cirp + (size_t)g.copad * (stride == 1 ? P : P / 2)) * 4;
+        STEP_REQUIRE(g.lds1 <= 160 * 1024,
+                     "step_gcn_bwd: residual conv with Ci=%d Co=%d stride=%d needs %zu bytes of LDS", Ci, Co, stride,
+                     g.lds1);
+        int per = (int)((160 * 1024) / g.lds1);
+        per = per < 1 ? 1 : (per > 4 ? 4 : per);
+        if (256 * per < g.nblk1) g.nblk1 = 256 * per;
+    }
     GbParams p{};
     p.dy = dy; p.dres = dres; p.x = x; p.in_scale = in_scale; p.in_shift = in_shift; p.w = w; p.b = b;
     p.A = A_eff; p.res_w = res_w; p.dx = dx;
     p.part1 = (float*)ws;
-    p.part2 = p.part1 + (size_t)g.nblk1 * g.part1;
+    p.part2 = p.part1 + (size_t)nblk1_ws * g.part1;
     p.w_transposed = w_transposed; p.res_transposed = res_transposed;
     p.N = N; p.Ci = Ci; p.Co = Co; p.K = K; p.T = T; p.stride = stride; p.To = (T - 1) / stride + 1;
     p.tiles_per_seq = (T + TT - 1) / TT;
@@ -742,7 +761,7 @@ extern "C" int step_gcn_bwd(const float* dy, const float* dres, const float* x, 
     hipStream_t st = (hipStream_t)stream;
     int rc = dispatch_gb(p, g, st);
     if (rc) return rc;
-    float* tot1 = p.part2 + (size_t)g.nblk2 * g.part2;
+    float* tot1 = p.part2 + (size_t)g.nblk2 * g.part2;   // (workspace rows: nblk1_ws + nblk2 + 2)
     float* tot2 = tot1 + g.part1;
     hipLaunchKernelGGL(sum_rows_kernel, dim3(step::ceil_div((int)g.part1, 128)), dim3(128), 0, st, p.part1,
                        tot1, g.nblk1, (int)g.part1);
