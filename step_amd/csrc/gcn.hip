@@ -37,7 +37,7 @@ struct GcnParams {
 constexpr int GCN_TT = 8;             // frames per tile
 constexpr int GCN_P = GCN_TT * 16;    // positions per tile
 
-template <int EMAX, int MT>
+template <int EMAX, int MT, bool PF>
 __global__ __launch_bounds__(256) void gcn_fwd_kernel(GcnParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int Kq = p.K * p.Cip;
@@ -112,26 +112,67 @@ __global__ __launch_bounds__(256) void gcn_fwd_kernel(GcnParams p) {
     }
 
     // ---- persistent loop over (n, 8-frame) tiles ---------------------------------------
+    // the x tile of the NEXT tile is fetched into registers (raw) before this tile's MFMA phase, so
+    // its HBM latency hides under the matrix work even at one block per CU
+    constexpr int XN = PF ? 8 : 1;                        // float4 per thread: Cip <= 64
+    float4 xr[XN];
+    auto load_tile = [&](int tile) {
+        const int n = tile / p.tiles_per_seq;
+        const int t0 = (tile % p.tiles_per_seq) * GCN_TT;
+#pragma unroll
+        for (int i = 0; i < XN; ++i) {
+            const int f = tid + i * 256;
+            const int ci = f >> 5;
+            const int row = (f & 31) >> 2, vq = f & 3;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (f < p.Cip * 32 && ci < p.Ci && t0 + row < p.T)
+                v = *reinterpret_cast<const float4*>(
+                    p.x + (((size_t)n * p.Ci + ci) * p.T + t0 + row) * 16 + vq * 4);
+            xr[i] = v;
+        }
+    };
+    if (PF && (int)blockIdx.x < p.ntiles) load_tile(blockIdx.x);
     for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
         const int n = tile / p.tiles_per_seq;
         const int t0 = (tile % p.tiles_per_seq) * GCN_TT;
         __syncthreads();                                  // previous tile's readers are done
-        for (int f = tid; f < p.Cip * 32; f += 256) {
-            const int ci = f >> 5;
-            const int row = (f & 31) >> 2, vq = f & 3;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ci < p.Ci && t0 + row < p.T) {
-                v = *reinterpret_cast<const float4*>(
-                    p.x + (((size_t)n * p.Ci + ci) * p.T + t0 + row) * 16 + vq * 4);
-                if (p.in_scale) {
-                    const int g = vq * 4 * p.Ci + ci;
-                    v.x = v.x * p.in_scale[g] + p.in_shift[g];
-                    v.y = v.y * p.in_scale[g + p.Ci] + p.in_shift[g + p.Ci];
-                    v.z = v.z * p.in_scale[g + 2 * p.Ci] + p.in_shift[g + 2 * p.Ci];
-                    v.w = v.w * p.in_scale[g + 3 * p.Ci] + p.in_shift[g + 3 * p.Ci];
+        if constexpr (PF) {
+#pragma unroll
+            for (int i = 0; i < XN; ++i) {
+                const int f = tid + i * 256;
+                if (f < p.Cip * 32) {
+                    const int ci = f >> 5;
+                    const int row = (f & 31) >> 2, vq = f & 3;
+                    float4 v = xr[i];
+                    if (p.in_scale && ci < p.Ci && t0 + row < p.T) {
+                        const int g = vq * 4 * p.Ci + ci;
+                        v.x = v.x * p.in_scale[g] + p.in_shift[g];
+                        v.y = v.y * p.in_scale[g + p.Ci] + p.in_shift[g + p.Ci];
+                        v.z = v.z * p.in_scale[g + 2 * p.Ci] + p.in_shift[g + 2 * p.Ci];
+                        v.w = v.w * p.in_scale[g + 3 * p.Ci] + p.in_shift[g + 3 * p.Ci];
+                    }
+                    *reinterpret_cast<float4*>(xs + ci * GCN_P + row * 16 + vq * 4) = v;
                 }
             }
-            *reinterpret_cast<float4*>(xs + ci * GCN_P + row * 16 + vq * 4) = v;
+            if (tile + (int)gridDim.x < p.ntiles) load_tile(tile + gridDim.x);
+        } else {
+            for (int f = tid; f < p.Cip * 32; f += 256) {
+                const int ci = f >> 5;
+                const int row = (f & 31) >> 2, vq = f & 3;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ci < p.Ci && t0 + row < p.T) {
+                    v = *reinterpret_cast<const float4*>(
+                        p.x + (((size_t)n * p.Ci + ci) * p.T + t0 + row) * 16 + vq * 4);
+                    if (p.in_scale) {
+                        const int g = vq * 4 * p.Ci + ci;
+                        v.x = v.x * p.in_scale[g] + p.in_shift[g];
+                        v.y = v.y * p.in_scale[g + p.Ci] + p.in_shift[g + p.Ci];
+                        v.z = v.z * p.in_scale[g + 2 * p.Ci] + p.in_shift[g + 2 * p.Ci];
+                        v.w = v.w * p.in_scale[g + 3 * p.Ci] + p.in_shift[g + 3 * p.Ci];
+                    }
+                }
+                *reinterpret_cast<float4*>(xs + ci * GCN_P + row * 16 + vq * 4) = v;
+            }
         }
         __syncthreads();
 
@@ -235,14 +276,14 @@ size_t gcn_lds_bytes(const GcnParams& p, int emax) {
     return f * 4;
 }
 
-template <int EMAX, int MT>
-int launch_gcn(const GcnParams& p, hipStream_t st) {
+template <int EMAX, int MT, bool PF>
+int launch_gcn_pf(const GcnParams& p, hipStream_t st) {
     const size_t lds = gcn_lds_bytes(p, EMAX);
     if (lds > 160 * 1024) {
         step::set_error("step_gcn_fwd: needs %zu bytes of LDS (> 160 KiB) for Ci=%d Co=%d", lds, p.Ci, p.Co);
         return STEP_ERR_ARG;
     }
-    auto kern = gcn_fwd_kernel<EMAX, MT>;
+    auto kern = gcn_fwd_kernel<EMAX, MT, PF>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -259,6 +300,13 @@ int launch_gcn(const GcnParams& p, hipStream_t st) {
     return step::check_launch("step_gcn_fwd");
 }
 
+// one block per CU (big LDS image): prefetch the next x tile into registers
+template <int EMAX, int MT>
+int launch_gcn(const GcnParams& p, hipStream_t st) {
+    const bool one_per_cu = gcn_lds_bytes(p, EMAX) * 2 > 160 * 1024;
+    return one_per_cu ? launch_gcn_pf<EMAX, MT, true>(p, st) : launch_gcn_pf<EMAX, MT, false>(p, st);
+}
+
 }  // namespace
 
 extern "C" int step_gcn_fwd(const float* x, const float* in_scale, const float* in_shift,
@@ -270,7 +318,7 @@ extern "C" int step_gcn_fwd(const float* x, const float* in_scale, const float* 
     STEP_REQUIRE(N > 0 && Ci > 0 && Co > 0 && T > 0, "step_gcn_fwd: bad shape N=%d Ci=%d Co=%d T=%d", N,
                  Ci, Co, T);
     STEP_REQUIRE(K >= 1 && K <= 3, "step_gcn_fwd: K=%d partitions (1..3 supported)", K);
-    STEP_REQUIRE(Co <= 64, "step_gcn_fwd: Co=%d > 64 not built (the reference uses 3/32/64)", Co);
+    STEP_REQUIRE(Co <= 64 && Ci <= 64, "step_gcn_fwd: Ci=%d Co=%d > 64 not built (the reference uses 3/32/64)", Ci, Co);
     STEP_REQUIRE(stride == 1 || stride == 2, "step_gcn_fwd: stride %d", stride);
     STEP_REQUIRE(a_nnz_max >= 1 && a_nnz_max <= 16, "step_gcn_fwd: a_nnz_max=%d", a_nnz_max);
     STEP_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "step_gcn_fwd: in_scale/in_shift pair");
