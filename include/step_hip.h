@@ -219,6 +219,14 @@ int step_vae_loss(const float* x_in, const float* x_out, const float* mean, cons
                   float* loss, float* d_x_out, float* d_mean, float* d_lsig,
                   int N, int C, int T, int V, int Z, void* ws, size_t ws_bytes, void* stream);
 
+/* ------------------------------------------------------ input pipeline ----
+ * out[n, c, t, v] = SUM_d M[n][c][d] * (gaits[n, t, v, d] - gaits[n, t, 0, d]) + M[n][c][3]:
+ * the root-relative similarity alignment of utils/common.py:105-112 (first 48 features of
+ * get_affective_features, all utils/loader.py:37 keeps) fused with the (N,T,V*C) -> (N,C,T,V)
+ * reshape + moveaxis of utils/loader.py:65-66.  gaits (N,T,V,3), M (N,3,4) = [cR | t] of
+ * get_transformation (common.py:230-279, computed on the host), out (N,3,T,V).              */
+int step_pose_align(const float* gaits, const float* M, float* out, int N, int T, int V, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -43,6 +43,7 @@ SIGNATURES = {
     "step_tcn_wgrad_bf16": (I, [P, P, P, P, I, P, P, I, I, I, I, I, I, I, P, Z, P]),
     "step_vae_loss_ws_bytes": (Z, [I]),
     "step_vae_loss": (I, [P, P, P, P, F, P, P, P, P, I, I, I, I, I, P, Z, P]),
+    "step_pose_align": (I, [P, P, P, I, I, I, P]),
     "step_pool_fwd": (I, [P, P, I, I, I, P]),
     "step_pool_bwd": (I, [P, P, I, I, I, P]),
     "step_dense_fwd": (I, [P, P, P, I, P, I, I, I, P]),

@@ -450,9 +450,32 @@ def gen_vae_loss():
     save("cvae_vae_loss_train", **out)
 
 
+# --------------------------------------------------------------------------- 10
+def gen_pose_align():
+    """the loader's Procrustes alignment, utils/common.py:91-112 (first 48 of the 175
+    features, the only ones utils/loader.py:37 keeps) with get_transformation (:230-279)."""
+    for k in list(sys.modules):
+        if k == "utils" or k.startswith("utils."):
+            del sys.modules[k]
+    sys.path[:] = [q for q in sys.path if not q.startswith(REF)]
+    sys.path.insert(0, os.path.join(REF, "classifier_stgcn_real_only"))
+    common = importlib.import_module("utils.common")
+    rng = np.random.default_rng(31)
+    base = rng.standard_normal((16, 3))                       # a "skeleton"
+    out = {}
+    for tag, (n, t) in {"a": (6, 10), "b": (3, 1)}.items():
+        rot = np.linalg.qr(rng.standard_normal((n, 3, 3)))[0]
+        gaits = (base[None, None] * rng.uniform(0.5, 2.0, (n, 1, 1, 1))) @ np.swapaxes(rot, 1, 2)[:, None]
+        gaits = gaits + rng.standard_normal((n, 1, 1, 3)) + 0.05 * rng.standard_normal((n, t, 16, 3))
+        feats = common.get_affective_features(gaits)
+        out[tag + ".gaits"] = gaits
+        out[tag + ".aligned"] = feats[:, :, :48].copy()
+    save("pose_align", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["graph", "gcn", "blocks", "ckpt", "train", "cvae", "hybrid", "vae_loss"]
+    which = sys.argv[1:] or ["graph", "gcn", "blocks", "ckpt", "train", "cvae", "hybrid", "vae_loss", "pose"]
     fns = dict(graph=gen_graph, gcn=gen_gcn, blocks=gen_blocks, ckpt=gen_ckpt_and_eval,
-               train=gen_train_steps, cvae=gen_cvae, hybrid=gen_hybrid, vae_loss=gen_vae_loss)
+               train=gen_train_steps, cvae=gen_cvae, hybrid=gen_hybrid, vae_loss=gen_vae_loss, pose=gen_pose_align)
     for w in which:
         fns[w]()

@@ -1,5 +1,7 @@
 """CPU: the oracle (oracle/) against every golden vector produced by the real reference
 (tests/golden/make_golden.py).  This is what pins the oracle."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -223,3 +225,19 @@ def test_vae_loss_oracle_vs_reference(tag):
     if d["x_in"].shape[2] <= 3:     # the reference's own statement order, term by term
         ref = losses.between_frame_loss_loops(d["x_in"], d["x_out"])
         assert abs(float(ref) - float(d["bf"])) <= 1e-6 * max(1.0, abs(float(d["bf"])))
+
+
+# ------------------------------------------------------------- pose alignment
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_pose_alignment_oracle_and_host_transforms_vs_reference(tag):
+    """common.py:91-112 (first 48 features) + get_transformation :230-279"""
+    from oracle import pose
+    from step_amd import pipeline
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "pose_align.npz"))
+    gaits, ref = z[tag + ".gaits"], z[tag + ".aligned"]
+    assert np.abs(pose.align_gaits(gaits) - ref).max() < 1e-12
+    # the product's batched host part (one SVD call for all gaits) gives the same transforms
+    M = pipeline.similarity_transforms(gaits)
+    for s in range(gaits.shape[0]):
+        R, c, t = pose.get_transformation(pose.get_joints(gaits, s, 0).T, pose.get_joints(gaits, 0, 0).T)
+        assert np.abs(M[s, :, :3] - c * R).max() < 1e-10 and np.abs(M[s, :, 3] - t).max() < 1e-10
