@@ -1,5 +1,5 @@
 """GPU: pose alignment + layout change against the reference's own output.
-(kept out of pytest's collection until it has passed on the GPU box; run by naming this file)"""
+
 import pytest
 import torch
 
