@@ -1,5 +1,4 @@
-"""GPU: pose alignment + layout change against the reference's own output.
-
+"""GPU: pose alignment + layout change against the reference's own output."""
 import pytest
 import torch
 
