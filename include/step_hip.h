@@ -227,6 +227,19 @@ int step_vae_loss(const float* x_in, const float* x_out, const float* mean, cons
  * get_transformation (common.py:230-279, computed on the host), out (N,3,T,V).              */
 int step_pose_align(const float* gaits, const float* M, float* out, int N, int T, int V, void* stream);
 
+/* ------------------------------------------------ affective features ----
+ * feat[n, :] = compute_features(gaits[n], time_step, add_stride_features) of
+ * compute_aff_features/compute_features.py:428-468 (helpers compute_aff_features/utils.py:3-34): box
+ * volume, 5 angles, 4 distances, 2 Heron areas, mean speed / acceleration / jerk magnitude of hands,
+ * head and feet (27 values), + stride length and gait-cycle time (:393-425) when add_stride_features.
+ * gaits (N,T,48) float32 or float64 (in_f64), feat (N, 27 | 29) float64; float64 arithmetic as in the
+ * reference; means over an empty set (T < 4) are NaN as numpy's.                                    */
+int step_aff_features(const void* gaits, int in_f64, double* feat, int N, int T, double time_step,
+                      int add_stride_features, void* stream);
+/* compute_aff_features/normalize_features.py:1-22: out[n,j] = (feat[n,j] - (max_j+min_j)/2) /
+ * ((max_j-min_j)/2), 0 where max_j == min_j; min/max over the N rows.  out (N,F) float32 or float64. */
+int step_aff_normalize(const double* feat, void* out, int out_f64, int N, int F, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

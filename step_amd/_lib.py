@@ -15,6 +15,7 @@ P = ctypes.c_void_p
 I = ctypes.c_int
 F = ctypes.c_float
 Z = ctypes.c_size_t
+DBL = ctypes.c_double
 
 # name -> (restype, argtypes); must match include/step_hip.h
 SIGNATURES = {
@@ -44,6 +45,8 @@ SIGNATURES = {
     "step_vae_loss_ws_bytes": (Z, [I]),
     "step_vae_loss": (I, [P, P, P, P, F, P, P, P, P, I, I, I, I, I, P, Z, P]),
     "step_pose_align": (I, [P, P, P, I, I, I, P]),
+    "step_aff_features": (I, [P, I, P, I, I, DBL, I, P]),
+    "step_aff_normalize": (I, [P, P, I, I, I, P]),
     "step_pool_fwd": (I, [P, P, I, I, I, P]),
     "step_pool_bwd": (I, [P, P, I, I, I, P]),
     "step_dense_fwd": (I, [P, P, P, I, P, I, I, I, P]),

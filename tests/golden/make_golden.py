@@ -473,9 +473,47 @@ def gen_pose_align():
     save("pose_align", **out)
 
 
+# --------------------------------------------------------------------------- 11
+def gen_affective():
+    """compute_aff_features/compute_features.py:428-468 (27 posture/movement features per
+    gait, 29 with the stride features) and normalize_features.py:1-22 (min-max to [-1, 1] over the set)."""
+    sys.path[:] = [q for q in sys.path if not q.startswith(REF)]
+    sys.path.insert(0, REF)
+    cf = importlib.import_module("compute_aff_features.compute_features")
+    nf = importlib.import_module("compute_aff_features.normalize_features")
+    ts = 1.0 / 30.0                                              # compute_aff_features/main.py:19
+    rng = np.random.default_rng(47)
+    _, h5g, _ = load_h5_gaits()                                  # the 60 shipped gaits, (60, 18, 48) f64
+    walk = np.cumsum(0.3 * rng.standard_normal((12, 64, 48)), axis=1) + 5.0 * rng.standard_normal((12, 1, 48))
+    # foot heights on a coarse grid: plateaus and ties exercise every branch of the strike-point rule
+    for j in (12, 15):
+        walk[:, :, 3 * j + 1] = np.round(walk[:, :, 3 * j + 1])
+    walk[3, :, 3 * 12 + 1] = 1.0                                 # right foot never moves: one strike run
+    walk[4, :, 3 * 12 + 1] = np.arange(64)                       # right foot rises monotonically: < 2 strikes
+    walk[4, :, 3 * 15 + 1] = -np.arange(64)                      # ... and so does the left: "no stride" branch
+    walk[5, :, 3 * 15 + 1] = np.arange(64)                       # left foot only
+    short = rng.standard_normal((5, 4, 48))                      # T = 4: one jerk sample
+    mono = rng.standard_normal((3, 6, 48))
+    mono[1, 2, 0::3] = -np.arange(16.0)                          # x strictly decreasing over the joints of a frame:
+    out = {}                                                     # the elif of :21-24 never runs, max stays -inf
+    for tag, g in {"h5": h5g, "walk": walk, "short": short, "mono": mono}.items():
+        with np.errstate(all="ignore"):
+            f27 = np.asarray([cf.compute_features(x, ts) for x in g], dtype=np.float64)
+            f29 = np.asarray([cf.compute_features(x, ts, add_stride_features=True) for x in g], dtype=np.float64)
+            rows = [["k%d" % i] + list(r) for i, r in enumerate(f29)]
+            normed = []
+            nf.normalize_features(rows, normed)
+        out[tag + ".gaits"] = g
+        out[tag + ".f27"] = f27
+        out[tag + ".f29"] = f29
+        out[tag + ".norm29"] = np.asarray([r[1:] for r in normed], dtype=np.float64)
+    save("affective", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["graph", "gcn", "blocks", "ckpt", "train", "cvae", "hybrid", "vae_loss", "pose"]
+    which = sys.argv[1:] or ["graph", "gcn", "blocks", "ckpt", "train", "cvae", "hybrid", "vae_loss", "pose", "affective"]
     fns = dict(graph=gen_graph, gcn=gen_gcn, blocks=gen_blocks, ckpt=gen_ckpt_and_eval,
-               train=gen_train_steps, cvae=gen_cvae, hybrid=gen_hybrid, vae_loss=gen_vae_loss, pose=gen_pose_align)
+               train=gen_train_steps, cvae=gen_cvae, hybrid=gen_hybrid, vae_loss=gen_vae_loss, pose=gen_pose_align,
+               affective=gen_affective)
     for w in which:
         fns[w]()

@@ -241,3 +241,31 @@ def test_pose_alignment_oracle_and_host_transforms_vs_reference(tag):
     for s in range(gaits.shape[0]):
         R, c, t = pose.get_transformation(pose.get_joints(gaits, s, 0).T, pose.get_joints(gaits, 0, 0).T)
         assert np.abs(M[s, :, :3] - c * R).max() < 1e-10 and np.abs(M[s, :, 3] - t).max() < 1e-10
+
+
+# -------------------------------------------------------- affective features
+def _same(got, ref, rtol):
+    """equal where the reference is finite (to rtol of the column scale), same NaN / +-inf elsewhere"""
+    got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    assert got.shape == ref.shape
+    fin = np.isfinite(ref)
+    assert np.array_equal(np.isnan(got), np.isnan(ref)) and np.array_equal(got[~fin & ~np.isnan(ref)],
+                                                                         ref[~fin & ~np.isnan(ref)])
+    scale = np.maximum(np.abs(np.where(fin, ref, 0.0)).max(axis=0, keepdims=True), 1e-30)
+    err = np.where(fin, np.abs(np.where(fin, got, 0.0) - np.where(fin, ref, 0.0)) / scale, 0.0)
+    assert err.max() <= rtol, "max error / column scale = %.3e > %.1e" % (err.max(), rtol)
+
+
+@pytest.mark.parametrize("tag", ["h5", "walk", "short", "mono"])
+def test_affective_features_oracle_vs_reference(tag):
+    """compute_features.py:428-468 and normalize_features.py:1-22 on the shipped 60 gaits and on seeded
+    gaits that reach every branch (plateaus and ties of the strike rule, a foot that never strikes,
+    T = 4, a frame whose box is not a bounding box)"""
+    from oracle import affective
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "affective.npz"))
+    g, ts = z[tag + ".gaits"], 1.0 / 30.0
+    _same(affective.compute_features_batch(g, ts), z[tag + ".f27"], 1e-10)
+    f29 = affective.compute_features_batch(g, ts, True)
+    _same(f29, z[tag + ".f29"], 1e-10)
+    assert np.array_equal(f29[:, 27], z[tag + ".f29"][:, 27])          # stride length: exact
+    _same(affective.normalize_features(z[tag + ".f29"]), z[tag + ".norm29"], 1e-12)

@@ -1,0 +1,152 @@
+#!/usr/bin/env python3
+"""Single-GPU throughput of every GPU configuration BASELINE.json names (configs[1..4]), beside the
+headline of bench.py.  One JSON object per configuration, one per line; each states the algorithmic
+FLOPs per sequence it was priced with and the fraction of the fp32 (or nominal bf16) MFMA peak.
+
+    python tools/bench_configs.py [--reps 3] [--only 2,3,4,5]
+
+configs[1]  real_only classifier inference, N=4096 x 3 x 240 x 16 fp32, eval mode
+configs[2]  real_and_synth training step, bf16 MFMA operands, per-GPU batch 512, T=240, Adam
+configs[3]  CVAE decoder bulk synthesis, micro-batch 2048, T=75 (12 500 gaits per GPU of the 100k job)
+configs[4]  hybrid classifier eval, N=1024, T=1024, F=27 affective features
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32 = 157.3e12
+PEAK_BF16 = 2500.0e12
+D = torch.device("cuda:0")
+
+
+def stack_flops(widths, strides, T, kt=75, res=None, K=3, V=16):
+    """algorithmic forward FLOPs of one sequence (SURVEY 8d formulas)"""
+    fl, t = 0.0, T
+    for i, ((ci, co), s) in enumerate(zip(widths, strides)):
+        to = (t - 1) // s + 1
+        fl += 2.0 * ci * K * co * t * V            # 1x1 conv to K*Co
+        fl += 2.0 * 46 / 16 * co * t * V           # aggregation over the 46 non-zeros of A (per w: 46/16)
+        fl += 2.0 * co * co * kt * to * V          # temporal conv
+        if res is None or res[i]:
+            if ci != co or s != 1:
+                fl += 2.0 * ci * co * to * V       # residual 1x1
+        t = to
+    return fl
+
+
+def timeit(fn, reps):
+    fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+
+def init_like_reference(m):
+    with torch.no_grad():
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Conv2d):
+                mod.weight.normal_(0.0, 0.02)
+                mod.bias.zero_()
+            elif isinstance(mod, torch.nn.modules.batchnorm._BatchNorm):
+                mod.weight.normal_(1.0, 0.02)
+                mod.bias.zero_()
+    return m
+
+
+def config2(reps):
+    from step_amd.net.classifier import Classifier
+    torch.manual_seed(0)
+    m = init_like_reference(Classifier(3, 4, {"strategy": "spatial"})).to(D).eval()
+    n, t = 4096, 240
+    x = (torch.randn(n, 3, t, 16, 1, generator=torch.Generator().manual_seed(1234)) * 0.5).to(D)
+    with torch.no_grad():
+        dt = timeit(lambda: m(x), reps)
+    fl = stack_flops([(3, 32), (32, 64), (64, 64)], [1, 2, 1], t)
+    return {"config": "configs[1] real_only inference N=4096 x 3 x 240 x 16 fp32 eval", "sequences_per_s": n / dt,
+            "ms": dt * 1e3, "gflop_per_seq": fl / 1e9, "frac_fp32_mfma": n * fl / dt / PEAK_FP32}
+
+
+def config3(reps):
+    import step_amd
+    from step_amd.net.classifier_real_and_synth import Classifier
+    torch.manual_seed(0)
+    n, t = 512, 240
+    fl = 3 * stack_flops([(3, 32), (32, 64), (64, 64)], [1, 2, 2], t, res=[False, True, True])
+    out = []
+    for mode in ("bf16", "f32"):
+        m = init_like_reference(Classifier(3, 4, {"strategy": "spatial"})).to(D).train()
+        step_amd.set_mfma_dtype(m, mode)
+        opt = torch.optim.Adam(m.parameters(), lr=0.1, weight_decay=1e-4)
+        g = torch.Generator().manual_seed(1234)
+        x = (torch.randn(n, 3, t, 16, 1, generator=g) * 0.5).to(D)
+        y = torch.randint(0, 4, (n,), generator=g).to(D)
+
+        def step():
+            o, _ = m(x)
+            loss = F.cross_entropy(o, y)
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            opt.step()
+        dt = timeit(step, reps)
+        peak = PEAK_BF16 if mode == "bf16" else PEAK_FP32
+        out.append({"config": "configs[2] real_and_synth train step (fwd+CE+bwd+Adam), per-GPU batch 512, T=240, "
+                              "%s MFMA operands" % mode, "sequences_per_s": n / dt, "ms": dt * 1e3,
+                    "gflop_per_seq_fwd_bwd": fl / 1e9, "frac_%s_mfma" % mode: n * fl / dt / peak})
+    return out
+
+
+def config4(reps):
+    from step_amd.net.CVAE_stgcn import CVAE
+    torch.manual_seed(0)
+    m = CVAE(3, 75, 16, 32, 4, {"strategy": "spatial"}).to(D).eval()
+    n, t = 2048, 75
+    z = (torch.randn(n, 32, generator=torch.Generator().manual_seed(5)) * 3 - 1.5).to(D)     # processor_stgcn.py:319
+    l = F.one_hot(torch.arange(n) % 4, 4).float().to(D)
+    with torch.no_grad():
+        dt = timeit(lambda: m.decoder(z, l, t, 16), reps)
+    fl = stack_flops([(32, 32), (32, 64), (64, 3)], [1, 1, 1], t)
+    return {"config": "configs[3] CVAE decoder synthesis, micro-batch 2048, T=75, eval", "gaits_per_s": n / dt,
+            "ms": dt * 1e3, "seconds_for_12500_gaits": 12500 / (n / dt), "gflop_per_gait": fl / 1e9,
+            "frac_fp32_mfma": n * fl / dt / PEAK_FP32}
+
+
+def config5(reps):
+    from step_amd.net.classifier_hybrid import Classifier
+    torch.manual_seed(0)
+    m = init_like_reference(Classifier(3, 27, 4, {"strategy": "spatial"})).to(D).eval()
+    n, t = 1024, 1024
+    g = torch.Generator().manual_seed(9)
+    xa = (torch.rand(n, 27, generator=g) * 2 - 1).to(D)
+    xg = (torch.randn(n, 3, t, 16, 1, generator=g) * 0.5).to(D)
+    with torch.no_grad():
+        dt = timeit(lambda: m(xa, xg), reps)
+    fl = stack_flops([(3, 32), (32, 64), (64, 64)], [1, 2, 2], t, res=[False, True, True])
+    return {"config": "configs[4] hybrid eval N=1024, T=1024, F=27", "sequences_per_s": n / dt, "ms": dt * 1e3,
+            "gflop_per_seq": fl / 1e9, "frac_fp32_mfma": n * fl / dt / PEAK_FP32}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--only", default="2,3,4,5")
+    a = ap.parse_args()
+    torch.cuda.set_device(D)
+    for k in a.only.split(","):
+        r = {"2": config2, "3": config3, "4": config4, "5": config5}[k](a.reps)
+        for line in (r if isinstance(r, list) else [r]):
+            print(json.dumps({k2: (round(v, 4) if isinstance(v, float) else v) for k2, v in line.items()}), flush=True)
+
+
+if __name__ == "__main__":
+    main()
