@@ -136,6 +136,21 @@ def config5(reps):
             "gflop_per_seq": fl / 1e9, "frac_fp32_mfma": n * fl / dt / PEAK_FP32}
 
 
+def aff(reps):
+    """affective features + normalisation of N=4096 gaits x T=240 (HBM-bound: each coordinate once)"""
+    from step_amd import affective
+    n, t = 4096, 240
+    out = []
+    for dt_ in (torch.float32, torch.float64):
+        g = torch.cumsum(0.3 * torch.randn(n, t, 48, generator=torch.Generator().manual_seed(2)), 1).to(dt_).to(D)
+        for stride_f in (False, True):
+            dt = timeit(lambda: affective.normalize_features(affective.compute_features(g, 1 / 30.0, stride_f, D)), reps)
+            out.append({"config": "affective features + normalise, N=4096 x T=240 x 48 %s, stride features %s"
+                                  % (str(dt_).replace("torch.", ""), stride_f),
+                        "gaits_per_s": n / dt, "ms": dt * 1e3, "GBps_algorithmic": g.numel() * g.element_size() / dt / 1e9})
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=3)
@@ -143,7 +158,7 @@ def main():
     a = ap.parse_args()
     torch.cuda.set_device(D)
     for k in a.only.split(","):
-        r = {"2": config2, "3": config3, "4": config4, "5": config5}[k](a.reps)
+        r = {"2": config2, "3": config3, "4": config4, "5": config5, "aff": aff}[k](a.reps)
         for line in (r if isinstance(r, list) else [r]):
             print(json.dumps({k2: (round(v, 4) if isinstance(v, float) else v) for k2, v in line.items()}), flush=True)
 
