@@ -15,6 +15,7 @@
 // by each lane from the x tile in LDS with the <= EMAX non-zeros of column w of A_k held in
 // registers, so A lives entirely on chip.
 #include "common.h"
+#include <cstdlib>
 #include <type_traits>
 
 namespace {
@@ -307,6 +308,314 @@ int launch_gcn(const GcnParams& p, hipStream_t st) {
     return one_per_cu ? launch_gcn_pf<EMAX, MT, true>(p, st) : launch_gcn_pf<EMAX, MT, false>(p, st);
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Second form of the forward kernel for the wide blocks (Ci = 32 | 64, no data_bn on the load).
+// Conv-first on the matrix cores, aggregation on the lanes:
+//   h_k[c,(t,v)] = SUM_ci W[k*Co+c, ci] x[ci,t,v]          (MFMA; B operand = the x tile as it lies)
+//   y[c,(t,w)]   = SUM_k SUM_v h_k[c,(t,v)] A[k,v,w] + bterm[c,w]
+// The accumulator layout puts the 16 joints of a frame on 16 adjacent lanes, so the contraction over v is a
+// sum over DPP row rotations (row_ror) with per-lane coefficients A[k][joint the rotation brings][own joint];
+// rotations whose coefficient vector is all zero are skipped by a block-uniform branch (the skeleton's
+// partitions use 1 / 8 / 3 of the 16).  The three partitions and the residual 1x1 conv share one B read per
+// k-step, which makes the inner loop 3-4 MFMAs per LDS read.  Where the operands live:
+//   * W (and the residual conv's Wr) in REGISTERS for the life of the persistent block: a wave owns one
+//     32-row M tile, so its A operand of (k, k-step s) is one register;
+//   * the x tile arrives by LDS-DMA (global_load_lds_dwordx4: no VGPRs, no ds_write) into a double buffer,
+//     tile i+1 in flight while tile i is contracted - one barrier per tile, no exposed HBM latency.
+// Wave w: M tile w % MT, position group w / MT = 2*MT frames = MT column tiles of 2 frames x 16 joints.
+// RES: 0 none, 1 residual 1x1 conv at stride 1, 2 at stride 2 (MT == 2: the group's 2 even frames).
+template <int R>
+__device__ __forceinline__ float row_ror(float x) {
+    if (R == 0) return x;
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x120 + (R & 15), 0xF, 0xF, true));
+}
+
+template <int R, int END, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (R < END) {
+        f(std::integral_constant<int, R>{});
+        static_for<R + 1, END>(f);
+    }
+}
+
+// OCC blocks per CU: 2 where operands + accumulators fit 256 registers, else 1 (up to 512 with the AGPRs).
+template <int CIP, int MT, int RES>
+constexpr int gcn2_occ() { return (MT == 1 && (RES == 0 || CIP == 32)) ? 2 : 1; }
+
+template <int CIP, int MT, int RES>
+__global__ __launch_bounds__(256, (gcn2_occ<CIP, MT, RES>())) void gcn_fwd2_kernel(GcnParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int KS = CIP / 2;                          // k-steps (pairs of input channels)
+    float* xs = smem;                                    // [2][CIP][128]
+    float* cfs = xs + 2 * CIP * GCN_P;                   // [3][16 rotations][16 joints]
+    float* colsum = cfs + 768;                           // [3][16]
+    float* bterm = colsum + 3 * 16;                      // [32*MT][16]
+    float* brs = bterm + 32 * MT * 16;                   // [32*MT]
+    float* stage = brs + 32 * MT;                        // [4 waves][32 rows][32*MT]: output transpose
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int l31 = lane & 31;
+    const int half = lane >> 5;
+    const int w16 = lane & 15;
+    const int mt = wave % MT;
+    const int fbase = (wave / MT) * 2 * MT;              // first local frame of the wave's group
+    const int frow = fbase + (l31 >> 4);                 // + 2*j for column tile j
+
+    // x tile by LDS-DMA: one wave-instruction moves two channel rows (2 x 512 B = 8 frames x 16 joints)
+    auto issue_dma = [&](int tile, int buf) {
+        const int n = tile / p.tiles_per_seq;
+        const int t0 = (tile % p.tiles_per_seq) * GCN_TT;
+        int tf = t0 + ((lane & 31) >> 2);
+        tf = tf < p.T ? tf : p.T - 1;                    // frames past the end: any valid address, never stored
+#pragma unroll
+        for (int i = 0; i < CIP / 8; ++i) {
+            const int piece = wave * (CIP / 8) + i;
+            const int ch = 2 * piece + half;
+            const float* src = p.x + (((size_t)n * CIP + ch) * p.T + tf) * 16 + (lane & 3) * 4;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(xs + buf * CIP * GCN_P + piece * 256),
+                                             16, 0, 0);
+        }
+    };
+    if ((int)blockIdx.x < p.ntiles) issue_dma(blockIdx.x, 0);
+
+    // ---- one-time per block: rotation coefficients, bias term, operands in registers -------------
+    // cf[k][R] = A[k][v = joint of the lane row_ror:R brings here][w = own joint]
+    unsigned rmask[3] = {0u, 0u, 0u};
+    static_for<0, 16>([&](auto rt) {
+        constexpr int R = decltype(rt)::value;
+        const int src = __float_as_int(row_ror<R>(__int_as_float(w16)));
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float a = (k < p.K) ? p.A[(k * 16 + src) * 16 + w16] : 0.f;
+            if (tid < 16) cfs[(k * 16 + R) * 16 + w16] = a;
+            if (__ballot(a != 0.f) != 0ull) rmask[k] |= 1u << R;
+        }
+    });
+#pragma unroll
+    for (int k = 0; k < 3; ++k) rmask[k] = __builtin_amdgcn_readfirstlane(rmask[k]);
+    if (tid < 48) {
+        const int k = tid >> 4, w = tid & 15;
+        float cs = 0.f;
+        if (k < p.K)
+            for (int v = 0; v < 16; ++v) cs += p.A[(k * 16 + v) * 16 + w];
+        colsum[tid] = cs;
+    }
+    __syncthreads();
+    for (int e = tid; e < 32 * MT * 16; e += 256) {
+        const int c = e >> 4, w = e & 15;
+        float s = 0.f;
+        if (c < p.Co && p.b)
+            for (int k = 0; k < p.K; ++k) s += p.b[k * p.Co + c] * colsum[k * 16 + w];
+        bterm[e] = s;
+    }
+    for (int c = tid; c < 32 * MT; c += 256) brs[c] = (RES != 0 && c < p.Co && p.res_b) ? p.res_b[c] : 0.f;
+
+    float wreg[3][KS];
+    {
+        const int c = mt * 32 + l31;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const int ci = 2 * s + half;
+                float v = 0.f;
+                if (k < p.K && c < p.Co)
+                    v = p.w_transposed ? p.w[(size_t)ci * (p.K * p.Co) + k * p.Co + c]
+                                       : p.w[((size_t)k * p.Co + c) * CIP + ci];
+                wreg[k][s] = v;
+            }
+    }
+    float wres[RES ? KS : 1];
+    if constexpr (RES != 0) {
+        const int c = mt * 32 + l31;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int ci = 2 * s + half;
+            float v = 0.f;
+            if (c < p.Co) v = p.res_transposed ? p.res_w[(size_t)ci * p.Co + c] : p.res_w[(size_t)c * CIP + ci];
+            wres[s] = v;
+        }
+    }
+    __syncthreads();                                     // tables visible; the first x tile has landed (vmcnt 0)
+
+    constexpr int NRA = RES == 1 ? MT : 1;
+    constexpr int PW = 32 * MT;                          // positions per wave (2*MT frames x 16 joints)
+    constexpr int LPC = PW / 4;                          // lanes per channel row in a wide store
+    const int lch = lane / LPC, lq = lane % LPC;
+    // rows of PW floats from the wave's stage -> out[n, mt*32 + ch, tfirst .., :] as float4
+    auto wide_store = [&](const float* stg, float* out, int Tout, int tfirst, int pw, bool tok, int n) {
+#pragma unroll
+        for (int i = 0; i < LPC / 2; ++i) {
+            const int ch = i * (64 / LPC) + lch;
+            const float4 v = *reinterpret_cast<const float4*>(stg + ch * pw + lq * 4);
+            if (tok && mt * 32 + ch < p.Co)
+                *reinterpret_cast<float4*>(out + (((size_t)n * p.Co + mt * 32 + ch) * Tout + tfirst) * 16 + lq * 4) = v;
+        }
+    };
+    const int crow = mt * 32 + 4 * half;                 // + (r&3) + 8*(r>>2): this lane's accumulator rows
+    int buf = 0;
+    for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+        const int n = tile / p.tiles_per_seq;
+        const int t0 = (tile % p.tiles_per_seq) * GCN_TT;
+        if (tile + (int)gridDim.x < p.ntiles) issue_dma(tile + gridDim.x, buf ^ 1);
+        const float* xb = xs + buf * CIP * GCN_P;
+
+        f32x16 h[3][MT], ra[NRA];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int j = 0; j < MT; ++j) h[k][j][r] = 0.f;
+#pragma unroll
+            for (int j = 0; j < NRA; ++j) ra[j][r] = 0.f;
+        }
+        const float* xlane = xb + half * GCN_P + frow * 16 + w16;          // + s*2*128 per k-step, + j*32 per column tile
+        const float* xeven = xb + half * GCN_P + (fbase + 2 * (l31 >> 4)) * 16 + w16;   // RES == 2: the even frames
+        // B reads run one k-step ahead of the MFMAs; 3-4 MFMAs per read keep the stream MFMA-dense
+        float b[MT], be = 0.f;
+#pragma unroll
+        for (int j = 0; j < MT; ++j) b[j] = xlane[j * 32];
+        if constexpr (RES == 2) be = xeven[0];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            float bn[MT], ben = 0.f;
+            if (s + 1 < KS) {
+#pragma unroll
+                for (int j = 0; j < MT; ++j) bn[j] = xlane[(s + 1) * 2 * GCN_P + j * 32];
+                if constexpr (RES == 2) ben = xeven[(s + 1) * 2 * GCN_P];
+            }
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int j = 0; j < MT; ++j)
+                    h[k][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[k][s], b[j], h[k][j], 0, 0, 0);
+            if constexpr (RES == 1) {
+#pragma unroll
+                for (int j = 0; j < MT; ++j)
+                    ra[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wres[s], b[j], ra[j], 0, 0, 0);
+            } else if constexpr (RES == 2) {
+                ra[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wres[s], be, ra[0], 0, 0, 0);
+            }
+            if (s + 1 < KS) {
+#pragma unroll
+                for (int j = 0; j < MT; ++j) b[j] = bn[j];
+                be = ben;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+
+        // ---- aggregation over the joints of each frame (DPP rotations), bias term, store ----------------
+        // The next tile's DMA (issued before the k loop) is waited for HERE, before this tile's stores are
+        // issued: __syncthreads() with an LDS-DMA in flight drains vmcnt(0), which at the end of the tile would
+        // also wait for every store of the epilogue to reach L2 - several microseconds per tile at one wave per
+        // SIMD.  The barrier at the end of the tile is then a raw s_barrier.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+        // Stores go through a wave-private LDS stage: in the accumulator layout a lane holds ONE float of a
+        // (channel, frame) row, and 4-byte global stores are issue-bound (a wave-instruction costs about the
+        // same whatever its width); read back as float4 along the frame axis, one wave-instruction stores
+        // 1 KiB (64 / LPC channel rows of PW*4 contiguous bytes) instead of 256 B.
+        float* stg = stage + wave * (32 * PW);
+        {
+            float yv[MT][16];
+#pragma unroll
+            for (int j = 0; j < MT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) yv[j][r] = bterm[(crow + (r & 3) + 8 * (r >> 2)) * 16 + w16];
+            static_for<0, 3>([&](auto kt) {
+                constexpr int k = decltype(kt)::value;
+                static_for<0, 16>([&](auto rt) {
+                    constexpr int R = decltype(rt)::value;
+                    if ((rmask[k] >> R) & 1u) {
+                        const float c = cfs[(k * 16 + R) * 16 + w16];
+#pragma unroll
+                        for (int j = 0; j < MT; ++j)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) yv[j][r] = fmaf(c, row_ror<R>(h[k][j][r]), yv[j][r]);
+                    }
+                });
+            });
+#pragma unroll
+            for (int j = 0; j < MT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) stg[((r & 3) + 8 * (r >> 2) + 4 * half) * PW + j * 32 + l31] = yv[j][r];
+            wide_store(stg, p.y, p.T, t0 + fbase, PW, (t0 + fbase + lq / 4) < p.T, n);
+        }
+
+        // ---- residual 1x1 conv (temporal stride 1 | 2): accumulated beside the main product -------------
+        if constexpr (RES == 1) {
+#pragma unroll
+            for (int j = 0; j < MT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int cl = (r & 3) + 8 * (r >> 2) + 4 * half;
+                    stg[cl * PW + j * 32 + l31] = ra[j][r] + brs[mt * 32 + cl];
+                }
+            wide_store(stg, p.res_out, p.To, t0 + fbase, PW, (t0 + fbase + lq / 4) < p.T, n);
+        } else if constexpr (RES == 2) {
+            static_assert(RES != 2 || MT == 2, "stride-2 residual: 4 frames per wave");
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cl = (r & 3) + 8 * (r >> 2) + 4 * half;
+                stg[cl * 32 + l31] = ra[0][r] + brs[mt * 32 + cl];
+            }
+            // 32 channel rows x 2 output frames: 8 lanes per row
+            const int lch8 = lane >> 3, lq8 = lane & 7;
+            const bool tok = (t0 + fbase + 2 * (lq8 >> 2)) < p.T;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ch = i * 8 + lch8;
+                const float4 v = *reinterpret_cast<const float4*>(stg + ch * 32 + lq8 * 4);
+                if (tok && mt * 32 + ch < p.Co)
+                    *reinterpret_cast<float4*>(p.res_out + (((size_t)n * p.Co + mt * 32 + ch) * p.To + ((t0 + fbase) >> 1)) * 16 + lq8 * 4) = v;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                     // every wave's DMA has landed; this buffer is free
+        asm volatile("" ::: "memory");
+        buf ^= 1;
+    }
+}
+
+template <int CIP, int MT, int RES>
+int launch_gcn2(const GcnParams& p, hipStream_t st) {
+    const size_t lds = ((size_t)2 * CIP * GCN_P + 768 + 3 * 16 + 32 * MT * 17 + 4 * 32 * 32 * MT) * 4;
+    auto kern = gcn_fwd2_kernel<CIP, MT, RES>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            step::set_error("step_gcn_fwd: hipFuncSetAttribute(%zu): %s", lds, hipGetErrorString(e));
+            return STEP_ERR_LAUNCH;
+        }
+    }
+    int blocks = 256 * gcn2_occ<CIP, MT, RES>();
+    if (blocks > p.ntiles) blocks = p.ntiles;
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, st, p);
+    return step::check_launch("step_gcn_fwd");
+}
+
+// returns -1 when the shape is not one of the register-resident forms
+template <int CIP>
+int dispatch_gcn2(const GcnParams& p, hipStream_t st) {
+    const int mt = p.Copad / 32;
+    const int res = p.res_w ? p.stride : 0;
+    if (mt == 1) {
+        if (res == 0) return launch_gcn2<CIP, 1, 0>(p, st);
+        if (res == 1) return launch_gcn2<CIP, 1, 1>(p, st);
+        return -1;
+    }
+    if (res == 0) return launch_gcn2<CIP, 2, 0>(p, st);
+    if (res == 1) return launch_gcn2<CIP, 2, 1>(p, st);
+    return launch_gcn2<CIP, 2, 2>(p, st);
+}
+
 }  // namespace
 
 extern "C" int step_gcn_fwd(const float* x, const float* in_scale, const float* in_shift,
@@ -335,6 +644,10 @@ extern "C" int step_gcn_fwd(const float* x, const float* in_scale, const float* 
     p.ntiles = (int)nt;
     hipStream_t st = (hipStream_t)stream;
     const int mt = p.Copad / 32;
+    if (!in_scale && (Ci == 32 || Ci == 64) && !getenv("STEP_GCN_FWD_V1")) {
+        const int rc = Ci == 32 ? dispatch_gcn2<32>(p, st) : dispatch_gcn2<64>(p, st);
+        if (rc != -1) return rc;
+    }
     if (a_nnz_max <= 4) return mt == 1 ? launch_gcn<4, 1>(p, st) : launch_gcn<4, 2>(p, st);
     return mt == 1 ? launch_gcn<16, 1>(p, st) : launch_gcn<16, 2>(p, st);
 }

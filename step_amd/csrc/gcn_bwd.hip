@@ -68,7 +68,7 @@ __device__ __forceinline__ float4 load_x4(const GbParams& p, int n, int ci, int 
 template <int R>
 __device__ __forceinline__ float row_ror(float x) {
     if (R == 0) return x;
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x120 + (R & 15), 0xF, 0xF, false));
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x120 + (R & 15), 0xF, 0xF, true));
 }
 
 template <int R, int END, typename F>

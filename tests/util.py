@@ -46,6 +46,18 @@ def feeds_train_bn(name):
     return name.endswith(("gcn.conv.bias", "gctn.conv.bias", "tcn.2.bias", "residual.0.bias"))
 
 
+def grad_noise(name):
+    """absolute rounding-noise floor of a parameter gradient in the train-step fixtures: conv biases in front
+    of a train-mode BN have a mathematically zero gradient, and data_bn's scale/shift gradients are sums of
+    nearly cancelling terms (block 0's BN1 undoes most of a per-(v,c) rescale), so their fp32 value moves
+    by ~1e-6 with the summation order of any implementation"""
+    if feeds_train_bn(name):
+        return 2e-6
+    if name.startswith(("data_bn.", "data_bn1.", "encoder.data_bn.")):
+        return 1e-6
+    return 2e-7
+
+
 def assert_grad_close(g, ref, rtol, name, noise=0.0):
     g = torch.as_tensor(g).double().cpu()
     ref = torch.as_tensor(ref).double().cpu()

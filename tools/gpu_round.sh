@@ -3,7 +3,7 @@
 set -e
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-timeout -k 10 900 python -u -m pytest tests -m gpu -x -q --timeout 120 --timeout-method thread tests/wip_pose_gpu.py > gpurun_out/pytest_gpu.log 2>&1 || { tail -30 gpurun_out/pytest_gpu.log; exit 1; }
+timeout -k 10 900 python -u -m pytest tests -m gpu -x -q --timeout 120 --timeout-method thread > gpurun_out/pytest_gpu.log 2>&1 || { tail -30 gpurun_out/pytest_gpu.log; exit 1; }
 tail -3 gpurun_out/pytest_gpu.log
 timeout -k 10 300 python -u __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1 || { tail -20 gpurun_out/smoke.log; exit 1; }
 tail -1 gpurun_out/smoke.log
