@@ -43,6 +43,7 @@ struct TcnParams {
     float* out;
     int in_relu, out_relu;
     int N, Cin, Cout, Cpad, PH, Tin, Tout, R, padL, nRB;
+    int NG;             // groups of 32*MW output rows (wide layers: PH*Cpad > 128); blockIdx.y
 };
 
 template <int NT, int KS, int STRIDE, int MW, int NW>
@@ -65,7 +66,7 @@ struct TcnCfg {
 };
 
 template <int NT, int KS, int STRIDE, int MW, int NW>
-__global__ __launch_bounds__(64 * MW * NW, (MW * NW >= 8) ? 2 : 2) void tcn_conv_kernel(TcnParams p) {
+__global__ __launch_bounds__(64 * MW * NW, (2 * TcnCfg<NT, KS, STRIDE, MW, NW>::BUF * 4 > 80 * 1024) ? 1 : 2) void tcn_conv_kernel(TcnParams p) {
     using Cfg = TcnCfg<NT, KS, STRIDE, MW, NW>;
     __shared__ __attribute__((aligned(16))) float smem[2 * Cfg::BUF];
 
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(64 * MW * NW, (MW * NW >= 8) ? 2 : 2) void tcn_conv
     // wave-instruction, no VGPRs, no ds_write).  The image is a straight copy, so the lane-linear
     // destination is exactly right; the tail piece reads into the pad of the packed buffer.
     auto load_w = [&](int c, float* buf) {
-        const float* wsrc = p.wp + (size_t)c * Cfg::WCH + lane * 4;
+        const float* wsrc = p.wp + ((size_t)blockIdx.y * p.Cin + c) * Cfg::WCH + lane * 4;
 #pragma unroll
         for (int k = 0; k < Cfg::WPW; ++k) {
             const int piece = k * (MW * NW) + wave;
@@ -229,7 +230,7 @@ __global__ __launch_bounds__(64 * MW * NW, (MW * NW >= 8) ? 2 : 2) void tcn_conv
     const int trow = l31 >> 4;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const int m = mw * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int m = blockIdx.y * Cfg::MPAD + mw * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
         const int ph = m / p.Cpad;
         const int c = m - ph * p.Cpad;
         if (c >= p.Cout || ph >= p.PH) continue;
@@ -256,12 +257,14 @@ __global__ __launch_bounds__(64 * MW * NW, (MW * NW >= 8) ? 2 : 2) void tcn_conv
 __global__ void tcn_pack_kernel(const float* __restrict__ w, float* __restrict__ wp, int Co,
                                 int Ci, int Kt, int stride, int mode, PackGeom g) {
     const int mpad = g.ph * g.cpad;
+    const int mg = mpad > 128 ? 128 : mpad;            // rows per group (one block's M extent)
     const int total = g.cin_g * 2 * g.ks * mpad;
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
-        const int m = e % mpad;
-        const int jj = (e / mpad) % (2 * g.ks);
-        const int cg = e / (mpad * 2 * g.ks);          // GEMM input channel
-        wp[e] = pack_value(w, Co, Ci, Kt, stride, mode, g, cg, jj, m);
+        const int ml = e % mg;
+        const int jj = (e / mg) % (2 * g.ks);
+        const int cg = (e / (mg * 2 * g.ks)) % g.cin_g;     // GEMM input channel
+        const int grp = e / (mg * 2 * g.ks * g.cin_g);
+        wp[e] = pack_value(w, Co, Ci, Kt, stride, mode, g, cg, jj, grp * mg + ml);
     }
 }
 
@@ -275,7 +278,7 @@ int launch_tcn(const TcnParams& p, hipStream_t st) {
         step::set_error("step_tcn_conv: grid of %lld blocks out of range", blocks);
         return STEP_ERR_ARG;
     }
-    hipLaunchKernelGGL((tcn_conv_kernel<NT, KS, STRIDE, MW, NW>), dim3((unsigned)blocks),
+    hipLaunchKernelGGL((tcn_conv_kernel<NT, KS, STRIDE, MW, NW>), dim3((unsigned)blocks, (unsigned)p.NG),
                        dim3(Cfg::NTHR), 0, st, q);
     return step::check_launch("step_tcn_conv");
 }
@@ -330,10 +333,21 @@ extern "C" int step_tcn_conv(const float* in, const float* in_scale, const float
     p.Tin = dgrad ? Tout : Tin;                 // rows of the tensor being read
     p.Tout = dgrad ? Tin : Tout;                // rows of the tensor being written
     p.R = step::ceil_div(p.Tout, g.ph);
-    const int mw = g.ph * g.cpad / 32;
+    int mw = g.ph * g.cpad / 32;
+    p.NG = 1;
+    if (mw > 4) {                               // wide layers: groups of 128 output rows on blockIdx.y
+        STEP_REQUIRE(mw % 4 == 0 && mw / 4 <= 65535, "step_tcn_conv: %d output rows are not a multiple of 128",
+                     g.ph * g.cpad);
+        p.NG = mw / 4;
+        mw = 4;
+    }
     const int key = g.ks * 100 + g.stride_g * 10 + mw;
     hipStream_t st = (hipStream_t)stream;
     switch (key) {
+        case 3814: return launch_tcn<5, 38, 1, 4, 2>(p, st);
+        case 3824: return launch_tcn<5, 38, 2, 4, 2>(p, st);
+        case 514: return launch_tcn<5, 5, 1, 4, 2>(p, st);
+        case 524: return launch_tcn<5, 5, 2, 4, 2>(p, st);
         case 3811: return launch_tcn<5, 38, 1, 1, 4>(p, st);
         case 3812: return launch_tcn<5, 38, 1, 2, 2>(p, st);
         case 3821: return launch_tcn<5, 38, 2, 1, 4>(p, st);

@@ -342,8 +342,8 @@ int step::wgrad_reduce(const float* slab, const float* dbslab, float* dw, float*
 extern "C" size_t step_tcn_wgrad_ws_bytes(int N, int Ci, int Co, int Tin, int Tout, int Kt) {
     WgGeom g;
     (void)Tin; (void)Tout;
-    if (!wg_geom(N, Ci, Co, Kt, 1, &g)) return 0;
-    size_t need = g.ws;                                 // nsplit does not depend on the stride
+    // wide layers (Co > 64) exist in the sliding-window form only
+    size_t need = wg_geom(N, Ci, Co, Kt, 1, &g) ? g.ws : 0;   // nsplit does not depend on the stride
     for (int s = 1; s <= 2; ++s) {                      // the sliding-window variant, where it applies
         const size_t sw = step::wgrad_sw_ws_bytes(N, Ci, Co, Kt, s);
         need = sw > need ? sw : need;
@@ -362,8 +362,19 @@ extern "C" int step_tcn_wgrad(const float* dout, const float* in, const float* i
     STEP_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "step_tcn_wgrad: scale/shift pair");
     STEP_REQUIRE(!transposed || stride == 1, "step_tcn_wgrad: transposed needs stride 1");
     WgGeom g;
-    STEP_REQUIRE(wg_geom(N, Ci, Co, Kt, stride, &g), "step_tcn_wgrad: unsupported Ci=%d Co=%d Kt=%d", Ci,
-                 Co, Kt);
+    if (!wg_geom(N, Ci, Co, Kt, stride, &g)) {
+        // wide layers (Co > 64): the sliding-window form only
+        const size_t sw = step::wgrad_sw_ws_bytes(N, Ci, Co, Kt, stride);
+        STEP_REQUIRE(sw != 0, "step_tcn_wgrad: unsupported Ci=%d Co=%d Kt=%d", Ci, Co, Kt);
+        if (ws_bytes < sw) {
+            step::set_error("step_tcn_wgrad: workspace %zu < %zu bytes", ws_bytes, sw);
+            return STEP_ERR_WORKSPACE;
+        }
+        const int rc_sw = step::wgrad_sw(dout, in, in_scale, in_shift, in_relu, dw, db, N, Ci, Co, Tin, Tout, Kt,
+                                         stride, transposed, ws, ws_bytes, (hipStream_t)stream);
+        STEP_REQUIRE(rc_sw != 1, "step_tcn_wgrad: unsupported Ci=%d Co=%d Kt=%d", Ci, Co, Kt);
+        return rc_sw;
+    }
     if (ws_bytes < g.ws) {
         step::set_error("step_tcn_wgrad: workspace %zu < %zu bytes", ws_bytes, g.ws);
         return STEP_ERR_WORKSPACE;

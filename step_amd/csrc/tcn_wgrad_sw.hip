@@ -28,6 +28,7 @@ struct WsParams {
     int in_relu;
     int N, Ci, Co, Tin, Tout, Kt, pad;
     int Q, ntb, nqb, nsplit;
+    int ncib;           // input-channel blocks of 32; q-block = (tap block, ci block, co group of 32*MW)
 };
 
 template <int MW, int NJ, int STRIDE, int TT>
@@ -85,7 +86,8 @@ __global__ __launch_bounds__(512) void tcn_wgrad_sw_kernel(WsParams p) {
     const int qb = lb % p.nqb;
     const int split = lb / p.nqb;
     const int tb = qb % p.ntb;                        // tap block
-    const int ci0 = (qb / p.ntb) * 32;                // input-channel block
+    const int ci0 = ((qb / p.ntb) % p.ncib) * 32;     // input-channel block
+    const int co0 = (qb / (p.ntb * p.ncib)) * 32 * MW;   // output-channel group (wide layers: Co > 64)
     const int j0 = tb * C::TAPS;
     const int n0 = (int)((long long)p.N * split / p.nsplit);
     const int n1 = (int)((long long)p.N * (split + 1) / p.nsplit);
@@ -117,8 +119,8 @@ __global__ __launch_bounds__(512) void tcn_wgrad_sw_kernel(WsParams p) {
                     const int co = c / CPR, slot = c - co * CPR;
                     const int w = slot < CPR - 1 ? slot : 0;
                     const int t = t0 + (w >> 2);
-                    const float* src = (c < DCH && co < p.Co && t < p.Tout)
-                                           ? dbase + ((co * p.Tout + t) * 16 + (w & 3) * 4)
+                    const float* src = (c < DCH && co0 + co < p.Co && t < p.Tout)
+                                           ? dbase + (((co0 + co) * p.Tout + t) * 16 + (w & 3) * 4)
                                            : p.zeros;
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                                      (__attribute__((address_space(3))) void*)(img + piece * 1024),
@@ -176,7 +178,7 @@ __global__ __launch_bounds__(512) void tcn_wgrad_sw_kernel(WsParams p) {
             }
         };
 
-        const bool want_db = (qb == 0) && p.dbslab;
+        const bool want_db = (qb % (p.ntb * p.ncib) == 0) && p.dbslab;     // one q-block per output group
         auto dbuf = [&](int item) { return smem + (item & 1) * C::D_BYTES; };
         auto abuf = [&](int item) { return smem + C::A_BASE + (item & 1) * C::A_BYTES; };
         if (total > 0) { dma_dout(0, dbuf(0)); dma_act(0, abuf(0)); }
@@ -193,7 +195,7 @@ __global__ __launch_bounds__(512) void tcn_wgrad_sw_kernel(WsParams p) {
 #pragma unroll
             for (int o = 1; o < TPC; o <<= 1) sdb += __shfl_xor(sdb, o, 64);
             const int co = ptid / TPC;
-            if (ptid % TPC == 0 && co < p.Co) p.dbslab[(size_t)split * p.Co + co] = sdb;
+            if (ptid % TPC == 0 && co0 + co < p.Co) p.dbslab[(size_t)split * p.Co + co0 + co] = sdb;
         }
         return;
     }
@@ -305,7 +307,7 @@ __global__ __launch_bounds__(512) void tcn_wgrad_sw_kernel(WsParams p) {
             for (int m = 0; m < MW; ++m)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int co = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                     if (co < p.Co) slab[(size_t)co * p.Q + ci * p.Kt + j] = acc[m][i][r];
                 }
         }
@@ -318,11 +320,12 @@ struct WsGeom {
 };
 
 bool ws_geom(int N, int Ci, int Co, int Kt, int stride, WsGeom* g) {
-    if (Kt != 75 || N < 1 || (Ci != 32 && Ci != 64) || Ci != Co || (stride != 1 && stride != 2)) return false;
-    g->mw = Co / 32;
+    // 32 / 64 channels (the reference's widths) or wider in multiples of 64 (output-channel groups of 64)
+    if (Kt != 75 || N < 1 || Ci != Co || (Ci != 32 && Ci % 64 != 0) || (stride != 1 && stride != 2)) return false;
+    g->mw = Co == 32 ? 1 : 2;
     g->taps = 20;
     g->ntb = step::ceil_div(Kt, g->taps);
-    g->nqb = g->ntb * (Ci / 32);
+    g->nqb = g->ntb * (Ci / 32) * (Co / (32 * g->mw));
     int ns = 256 / g->nqb;                     // one block per CU
     ns = ns < 1 ? 1 : ns;
     g->nsplit = ns < N ? ns : N;
@@ -369,7 +372,7 @@ int step::wgrad_sw(const float* dout, const float* in, const float* in_scale, co
     p.zeros = zl;
     p.N = N; p.Ci = Ci; p.Co = Co; p.Tin = Tin; p.Tout = Tout; p.Kt = Kt;
     p.pad = (Kt - 1) / 2;
-    p.Q = Ci * Kt; p.ntb = g.ntb; p.nqb = g.nqb; p.nsplit = g.nsplit;
+    p.Q = Ci * Kt; p.ntb = g.ntb; p.nqb = g.nqb; p.nsplit = g.nsplit; p.ncib = Ci / 32;
     int rc;
     if (bf16) {
         if (g.mw == 1) rc = stride == 1 ? launch_ws<1, 5, 1, 6, true>(p, st) : launch_ws<1, 5, 2, 4, true>(p, st);

@@ -27,6 +27,9 @@ def A_spatial(dense=False, seed=0):
 @pytest.mark.parametrize("C,Co,Kt,stride,T,N", [
     (32, 32, 75, 1, 40, 2), (64, 64, 75, 1, 23, 2), (64, 64, 75, 2, 41, 2), (32, 32, 75, 2, 30, 1),
     (3, 3, 75, 1, 20, 2), (32, 32, 9, 1, 50, 2), (64, 64, 9, 2, 37, 2), (64, 64, 75, 1, 240, 1),
+    # wide layers (the reference's commented-out 128 / 256 blocks, classifier.py:42-49): output-row groups
+    (128, 128, 75, 1, 23, 2), (128, 128, 75, 2, 41, 1), (256, 256, 75, 1, 21, 1), (256, 256, 75, 2, 30, 1),
+    (128, 128, 9, 1, 50, 1), (256, 256, 9, 2, 37, 1),
 ])
 def test_tcn_forward_and_epilogue(C, Co, Kt, stride, T, N):
     from step_amd import ops
@@ -55,7 +58,9 @@ def test_tcn_forward_and_epilogue(C, Co, Kt, stride, T, N):
 
 
 @pytest.mark.parametrize("C,Kt,stride,T,N", [(32, 75, 1, 33, 2), (64, 75, 2, 41, 2), (64, 75, 2, 40, 1),
-                                             (32, 75, 2, 21, 2), (64, 9, 2, 30, 2), (3, 75, 1, 16, 2)])
+                                             (32, 75, 2, 21, 2), (64, 9, 2, 30, 2), (3, 75, 1, 16, 2),
+                                             (128, 75, 1, 33, 2), (128, 75, 2, 41, 1), (256, 75, 1, 20, 1),
+                                             (256, 75, 2, 30, 1)])
 def test_tcn_dgrad_and_wgrad(C, Kt, stride, T, N):
     from step_amd import ops
     g = torch.Generator().manual_seed(2)
