@@ -58,13 +58,19 @@ def tcn_flops(n, c, t_out, kt=75):
     return 2.0 * c * c * kt * t_out * 16 * n
 
 
-def time_kernels(n, t, device, reps=3, bf16=False):
+# north_star's wide layers (C = 128 / 256; the reference leaves these blocks commented out,
+# classifier_stgcn_real_only/net/classifier.py:42-49): (channels, stride, T_in) of the original ST-GCN schedule
+WIDE_BLOCKS = [(128, 2, 120), (128, 1, 60), (256, 2, 60), (256, 1, 30)]
+
+
+def time_kernels(n, t, device, reps=3, bf16=False, blocks=None, tag="b"):
     """HIP-event timing of each temporal-conv kernel of the step (fwd, dgrad, wgrad x 3 blocks),
     launched alone on the current stream."""
     from step_amd import ops
     out = []
     peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
-    blocks = [(32, 1, t), (64, 2, t), (64, 1, (t - 1) // 2 + 1)]
+    if blocks is None:
+        blocks = [(32, 1, t), (64, 2, t), (64, 1, (t - 1) // 2 + 1)]
     g = torch.Generator().manual_seed(7)
     for bi, (c, s, tin) in enumerate(blocks):
         tout = (tin - 1) // s + 1
@@ -95,7 +101,7 @@ def time_kernels(n, t, device, reps=3, bf16=False):
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / reps
             fl = tcn_flops(n, c, tout)
-            out.append({"kernel": "%s_b%d" % (name, bi), "C": c, "stride": s, "ms": round(ms, 3),
+            out.append({"kernel": "%s_%s%d" % (name, tag, bi), "C": c, "stride": s, "T_in": tin, "ms": round(ms, 3),
                         "tflops": round(fl / ms / 1e9, 2),
                         "frac": round(fl / ms / 1e9 / peak, 4)})
         del y, du
@@ -277,6 +283,9 @@ def main():
         dom = max(kernels, key=lambda k: k["ms"])
         torch.cuda.empty_cache()
         kernels = kernels + time_hbm_kernels(args.batch, args.frames, device)
+        if args.mfma == "f32":          # MFMA utilisation of the wide layers (kernel-level bench points, N = batch / 2)
+            torch.cuda.empty_cache()
+            kernels = kernels + time_kernels(max(1, args.batch // 2), args.frames, device, blocks=WIDE_BLOCKS, tag="wide")
         traffic = None
         try:    # HBM bytes per launch from the committed PMC passes (same shape, N=4096 only)
             with open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")) as fh:
