@@ -83,6 +83,17 @@ int step_bn_bwd_apply(const float* dy, const float* x, const float* mask_src,
                       float* dx, float* dgamma, float* dbeta,
                       int N, int C, int T, int V, int bn_mode,
                       void* ws, size_t ws_bytes, void* stream);
+/* Tail of a block with a residual conv, out = relu(bn2(u) + bn_r(r)) classifier.py:163,175-181,189-191:
+ * both BatchNorm backward passes (g = dout * (out > 0) for either) as one reduce and one apply, i.e.
+ * step_bn_bwd_reduce + step_bn_bwd_apply with mask_mode 1 for (u, BN2) and for (r, residual BN), sharing the
+ * reads of dout and out; results are bit-identical to the two separate calls.  bn_mode 0 only.
+ * ws: 2 * step_bn_ws_bytes(C) bytes.                                                              */
+int step_bn_bwd_tail_pair(const float* dout, const float* out, const float* u, const float* r,
+                          const float* mean_u, const float* invstd_u, const float* gamma_u,
+                          const float* mean_r, const float* invstd_r, const float* gamma_r,
+                          int training, float* du, float* dr, float* dgamma_u, float* dbeta_u,
+                          float* dgamma_r, float* dbeta_r, int N, int C, int T, int V,
+                          void* ws, size_t ws_bytes, void* stream);
 /* dx (+)= dy * (mask_src > 0): identity residual branch, classifier.py:170-171 */
 int step_masked_add(const float* dy, const float* mask_src, float* dx, int accumulate,
                     size_t n, void* stream);

@@ -249,6 +249,77 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     }
 }
 
+// ---- block tail with a residual conv: BN2 (of u) and the residual BN (of r) share dout and the ReLU
+// mask of `out`, so their backward passes run as ONE reduce and ONE apply (4 tensor reads instead of 6 in
+// each).  Same per-lane summation order as bn_reduce_kernel<true, 1>, so the sums are bit-identical.
+__global__ __launch_bounds__(BN_THREADS) void bn_reduce_pair_kernel(
+    const float* __restrict__ dy, const float* __restrict__ msrc, const float* __restrict__ xu,
+    const float* __restrict__ xr, double* __restrict__ part_u, double* __restrict__ part_r,
+    int N, int C, int T, int nchunks) {
+    const int c = blockIdx.x;
+    const int chunk = blockIdx.y;
+    const int n0 = (int)((long long)N * chunk / nchunks);
+    const int n1 = (int)((long long)N * (chunk + 1) / nchunks);
+    const int tid = threadIdx.x;
+    const int v0 = (tid & 3) * 4;
+    const int slot = tid >> 2;
+    float a[4] = {0.f, 0.f, 0.f, 0.f}, bu[4] = {0.f, 0.f, 0.f, 0.f}, br[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int n = n0; n < n1; ++n) {
+        const size_t base = ((size_t)n * C + c) * T * 16;
+        for (int t = slot; t < T; t += 64) {
+            const size_t o = base + (size_t)t * 16 + v0;
+            const float4 d = load4(dy + o), m = load4(msrc + o), u = load4(xu + o), r = load4(xr + o);
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 g = masked<1>(d, z, m, z, z);
+            a[0] += g.x; a[1] += g.y; a[2] += g.z; a[3] += g.w;
+            bu[0] += g.x * u.x; bu[1] += g.y * u.y; bu[2] += g.z * u.z; bu[3] += g.w * u.w;
+            br[0] += g.x * r.x; br[1] += g.y * r.y; br[2] += g.z * r.z; br[3] += g.w * r.w;
+        }
+    }
+    __shared__ double red[3][16][65];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        red[0][v0 + k][slot] = (double)a[k];
+        red[1][v0 + k][slot] = (double)bu[k];
+        red[2][v0 + k][slot] = (double)br[k];
+    }
+    __syncthreads();
+    if (tid < 48) {
+        const int which = tid >> 4, v = tid & 15;
+        double s = 0.0;
+        for (int k = 0; k < 64; ++k) s += red[which][v][k];
+        red[which][v][64] = s;
+    }
+    __syncthreads();
+    if (tid < 3) {
+        double s = 0.0;
+        for (int v = 0; v < 16; ++v) s += red[tid][v][64];
+        const size_t e = ((size_t)chunk * C + c) * 2;
+        if (tid == 0) { part_u[e] = s; part_r[e] = s; }
+        else if (tid == 1) part_u[e + 1] = s;
+        else part_r[e + 1] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_pair_kernel(
+    const float* __restrict__ dy, const float* __restrict__ msrc, const float* __restrict__ xu,
+    const float* __restrict__ xr, const float* __restrict__ coef_u, const float* __restrict__ coef_r,
+    float* __restrict__ du, float* __restrict__ dr, size_t n4, int C, int T) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)((i >> 2) / T % C);
+        const float4 d = load4(dy + i * 4), m = load4(msrc + i * 4), u = load4(xu + i * 4), r = load4(xr + i * 4);
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 g = masked<1>(d, z, m, z, z);
+        const float au = coef_u[3 * c], bu = coef_u[3 * c + 1], cu = coef_u[3 * c + 2];
+        const float ar = coef_r[3 * c], br = coef_r[3 * c + 1], cr = coef_r[3 * c + 2];
+        *reinterpret_cast<float4*>(du + i * 4) = make_float4(g.x * au + u.x * bu + cu, g.y * au + u.y * bu + cu,
+                                                             g.z * au + u.z * bu + cu, g.w * au + u.w * bu + cu);
+        *reinterpret_cast<float4*>(dr + i * 4) = make_float4(g.x * ar + r.x * br + cr, g.y * ar + r.y * br + cr,
+                                                             g.z * ar + r.z * br + cr, g.w * ar + r.w * br + cr);
+    }
+}
+
 __global__ __launch_bounds__(256) void masked_add_kernel(const float* __restrict__ dy,
                                                          const float* __restrict__ msrc,
                                                          float* __restrict__ dx, int accumulate,
@@ -403,6 +474,43 @@ extern "C" int step_bn_bwd_apply(const float* dy, const float* x, const float* m
                                coef, accumulate, dx, n4, C, T, bn_mode);
     }
     return step::check_launch("step_bn_bwd_apply");
+}
+
+extern "C" int step_bn_bwd_tail_pair(const float* dout, const float* out, const float* u, const float* r,
+                                     const float* mean_u, const float* invstd_u, const float* gamma_u,
+                                     const float* mean_r, const float* invstd_r, const float* gamma_r,
+                                     int training, float* du, float* dr, float* dgamma_u, float* dbeta_u,
+                                     float* dgamma_r, float* dbeta_r, int N, int C, int T, int V, void* ws,
+                                     size_t wsb, void* stream) {
+    const int bn_mode = 0;
+    BN_SHAPE_CHECK("step_bn_bwd_tail_pair");
+    STEP_REQUIRE(dout && out && u && r && mean_u && invstd_u && mean_r && invstd_r && du && dr && ws,
+                 "step_bn_bwd_tail_pair: null pointer");
+    const size_t one = ws_bytes(C);
+    if (wsb < 2 * one) {
+        step::set_error("step_bn_bwd_tail_pair: workspace %zu < %zu bytes", wsb, 2 * one);
+        return STEP_ERR_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int nch = chunks_for(N);
+    const double count = (double)N * T * 16;
+    char* wsu = (char*)ws;
+    char* wsr = wsu + one;
+    auto part = [](char* w) { return (double*)w; };
+    auto tot = [&](char* w) { return (double*)w + (size_t)BN_MAX_CHUNKS * C * 2; };
+    auto coef = [&](char* w) { return (float*)((double*)w + (size_t)BN_MAX_CHUNKS * C * 2 + 2 * (size_t)C); };
+    hipLaunchKernelGGL(bn_reduce_pair_kernel, dim3(C, nch), dim3(BN_THREADS), 0, st, dout, out, u, r, part(wsu),
+                       part(wsr), N, C, T, nch);
+    hipLaunchKernelGGL(bn_sum_chunks_kernel, dim3(step::ceil_div(2 * C, 128)), dim3(128), 0, st, part(wsu), tot(wsu), C, nch);
+    hipLaunchKernelGGL(bn_sum_chunks_kernel, dim3(step::ceil_div(2 * C, 128)), dim3(128), 0, st, part(wsr), tot(wsr), C, nch);
+    hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3(step::ceil_div(C, 128)), dim3(128), 0, st, tot(wsu), mean_u, invstd_u,
+                       gamma_u, training, count, coef(wsu), dgamma_u, dbeta_u, C);
+    hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3(step::ceil_div(C, 128)), dim3(128), 0, st, tot(wsr), mean_r, invstd_r,
+                       gamma_r, training, count, coef(wsr), dgamma_r, dbeta_r, C);
+    const size_t n4 = (size_t)N * C * T * 4;
+    hipLaunchKernelGGL(bn_bwd_apply_pair_kernel, dim3(elem_grid(n4)), dim3(256), 0, st, dout, out, u, r, coef(wsu),
+                       coef(wsr), du, dr, n4, C, T);
+    return step::check_launch("step_bn_bwd_tail_pair");
 }
 
 extern "C" int step_masked_add(const float* dy, const float* mask_src, float* dx, int accumulate,

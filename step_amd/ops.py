@@ -92,6 +92,21 @@ def bn_backward(dy, x, mask_src, scale, shift, mask_mode, mean, invstd, gamma, t
     return dx, dgamma, dbeta
 
 
+def bn_backward_tail_pair(dout, out, u, r, m2, i2, g2, mr, ir, gr, training):
+    """(du, dgamma2, dbeta2, dr, dgamma_r, dbeta_r) of out = relu(bn2(u) + bn_r(r)): both BN backward passes
+    in one reduce + one apply (they share dout and the ReLU mask of out)"""
+    N, C, T, V = u.shape
+    dev = u.device
+    nb = 2 * _lib.query("step_bn_ws_bytes", C)
+    ws = _ws(nb, dev)
+    du, dr = torch.empty_like(u), torch.empty_like(r)
+    dg2 = torch.empty(C, dtype=torch.float32, device=dev)
+    db2, dgr, dbr = torch.empty_like(dg2), torch.empty_like(dg2), torch.empty_like(dg2)
+    _lib.call("step_bn_bwd_tail_pair", dout, out, u, r, m2, i2, g2, mr, ir, gr, int(training), du, dr,
+              dg2, db2, dgr, dbr, N, C, T, V, ws, nb)
+    return du, dg2, db2, dr, dgr, dbr
+
+
 # --------------------------------------------------------------------- temporal conv
 def tcn_bf16_supported(Co, Ci, Kt, stride, mode):
     """True when the bf16-operand MFMA kernels cover this temporal conv (else use fp32)."""
@@ -260,10 +275,11 @@ class StGcnBlockFn(torch.autograd.Function):
         dev = dout.device
 
         # tail: out = relu(bn2(u) + res)
-        du, dg2, db2 = bn_backward(dout, u, out, None, None, 1, m2, i2, bn2_w, training, 0)
         dr = dgr = dbr = None
         if s.residual == "conv":
-            dr, dgr, dbr = bn_backward(dout, r, out, None, None, 1, mr, ir, bnr_w, training, 0)
+            du, dg2, db2, dr, dgr, dbr = bn_backward_tail_pair(dout, out, u, r, m2, i2, bn2_w, mr, ir, bnr_w, training)
+        else:
+            du, dg2, db2 = bn_backward(dout, u, out, None, None, 1, m2, i2, bn2_w, training, 0)
 
         # temporal conv
         dtw, dtb = tcn_wgrad(du, y, s1, h1, True, N, Co, Co, T, To, Kt, st, s.transposed, tcn_w.shape,

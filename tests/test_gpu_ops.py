@@ -197,3 +197,24 @@ def test_heads():
     assert_close(xg.grad, xr.grad, 1e-4, "dx")
     assert_close(wg.grad, wr.grad, 1e-4, "dw")
     assert_close(bg.grad, br.grad, 1e-4, "db")
+
+
+@pytest.mark.parametrize("N,C,T,training", [(3, 5, 7, True), (300, 32, 11, True), (2, 64, 40, False)])
+def test_bn_backward_tail_pair_equals_two_passes(N, C, T, training):
+    """block tail with a residual conv: one fused reduce + apply for BN2 and the residual BN, bit-identical
+    to the two separate step_bn_bwd_reduce / step_bn_bwd_apply passes it replaces"""
+    from step_amd import ops
+    g = torch.Generator().manual_seed(6)
+    d = dev()
+    u, r = torch.randn(N, C, T, 16, generator=g).to(d), torch.randn(N, C, T, 16, generator=g).to(d)
+    out = torch.relu(torch.randn(N, C, T, 16, generator=g)).to(d)
+    dout = torch.randn(N, C, T, 16, generator=g).to(d)
+    w2, wr = (torch.rand(C, generator=g) + 0.5).to(d), (torch.rand(C, generator=g) + 0.5).to(d)
+    b, rm, rv = torch.zeros(C, device=d), torch.zeros(C, device=d), torch.ones(C, device=d)
+    m2, i2, _, _ = ops.bn_train_prepare(u, 0, w2, b, rm.clone(), rv.clone())
+    mr, ir, _, _ = ops.bn_train_prepare(r, 0, wr, b, rm.clone(), rv.clone())
+    ref_u = ops.bn_backward(dout, u, out, None, None, 1, m2, i2, w2, training, 0)
+    ref_r = ops.bn_backward(dout, r, out, None, None, 1, mr, ir, wr, training, 0)
+    got = ops.bn_backward_tail_pair(dout, out, u, r, m2, i2, w2, mr, ir, wr, training)
+    for a, b_ in zip(got, tuple(ref_u) + tuple(ref_r)):
+        assert torch.equal(a, b_)
