@@ -136,6 +136,41 @@ def config5(reps):
             "gflop_per_seq": fl / 1e9, "frac_fp32_mfma": n * fl / dt / PEAK_FP32}
 
 
+def kt9(reps):
+    """north_star's literal 9 x 1 temporal kernel (the reference uses 75; SURVEY 8d "extra bench points"):
+    real_only architecture at Kt = 9, N = 4096 x 3 x 240 x 16 - the model drops below the fp32 ridge only in
+    bf16, so the fp32 fractions are still against the MFMA peak; HBM bytes per sequence 7.22 MB forward."""
+    import step_amd
+    from step_amd.net.classifier import Classifier
+    torch.manual_seed(0)
+    n, t = 4096, 240
+    g = torch.Generator().manual_seed(1234)
+    x = (torch.randn(n, 3, t, 16, 1, generator=g) * 0.5).to(D)
+    y = torch.randint(0, 4, (n,), generator=g).to(D)
+    fl = stack_flops([(3, 32), (32, 64), (64, 64)], [1, 2, 1], t, kt=9)
+    out = []
+    m = init_like_reference(Classifier(3, 4, {"strategy": "spatial"}, temporal_kernel_size=9)).to(D).eval()
+    with torch.no_grad():
+        dt = timeit(lambda: m(x), reps)
+    out.append({"config": "Kt=9 real_only inference N=4096 x 3 x 240 x 16 fp32 eval", "sequences_per_s": n / dt, "ms": dt * 1e3,
+                "gflop_per_seq": fl / 1e9, "frac_fp32_mfma": n * fl / dt / PEAK_FP32,
+                "hbm_GBps_algorithmic": n * 7.22e6 / dt / 1e9})
+    m.train()
+    opt = torch.optim.Adam(m.parameters(), lr=0.1, weight_decay=1e-4)
+
+    def step():
+        o, _ = m(x)
+        loss = F.cross_entropy(o, y)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+    dt = timeit(step, reps)
+    out.append({"config": "Kt=9 real_only train step (fwd+CE+bwd+Adam) N=4096 x 3 x 240 x 16 fp32", "sequences_per_s": n / dt,
+                "ms": dt * 1e3, "gflop_per_seq_fwd_bwd": 3 * fl / 1e9, "frac_fp32_mfma": 3 * n * fl / dt / PEAK_FP32,
+                "hbm_GBps_algorithmic": 3 * n * 7.22e6 / dt / 1e9})
+    return out
+
+
 def aff(reps):
     """affective features + normalisation of N=4096 gaits x T=240 (HBM-bound: each coordinate once)"""
     from step_amd import affective
@@ -158,7 +193,7 @@ def main():
     a = ap.parse_args()
     torch.cuda.set_device(D)
     for k in a.only.split(","):
-        r = {"2": config2, "3": config3, "4": config4, "5": config5, "aff": aff}[k](a.reps)
+        r = {"2": config2, "3": config3, "4": config4, "5": config5, "aff": aff, "kt9": kt9}[k](a.reps)
         for line in (r if isinstance(r, list) else [r]):
             print(json.dumps({k2: (round(v, 4) if isinstance(v, float) else v) for k2, v in line.items()}), flush=True)
 
