@@ -311,45 +311,31 @@ int launch_gcn(const GcnParams& p, hipStream_t st) {
 
 // ------------------------------------------------------------------------------------------
 // Second form of the forward kernel for the wide blocks (Ci = 32 | 64, no data_bn on the load).
-// Conv-first on the matrix cores, aggregation on the lanes:
-//   h_k[c,(t,v)] = SUM_ci W[k*Co+c, ci] x[ci,t,v]          (MFMA; B operand = the x tile as it lies)
-//   y[c,(t,w)]   = SUM_k SUM_v h_k[c,(t,v)] A[k,v,w] + bterm[c,w]
-// The accumulator layout puts the 16 joints of a frame on 16 adjacent lanes, so the contraction over v is a
-// sum over DPP row rotations (row_ror) with per-lane coefficients A[k][joint the rotation brings][own joint];
-// rotations whose coefficient vector is all zero are skipped by a block-uniform branch (the skeleton's
-// partitions use 1 / 8 / 3 of the 16).  The three partitions and the residual 1x1 conv share one B read per
-// k-step, which makes the inner loop 3-4 MFMAs per LDS read.  Where the operands live:
+// Both contractions run on the matrix cores, and the first feeds the second without moving a byte:
+//   z_k[(ci,t), w] = SUM_v x[ci,t,v] A[k,v,w]      v_mfma_f32_16x16x4_f32: a 16-row z tile = 8 channels x 2 frames,
+//                                                  4 instructions (4 joints of v each); B operand = A_k (registers)
+//   y[c,(t,w)]    += SUM_ci W[k*Co+c, ci] z_k[..]  v_mfma_f32_32x32x2_f32
+// With row i = 4q + r of the z tile standing for (channel 2r + (q >> 1), frame q & 1), result register r of lane
+// 16q + w IS the B operand of the main product's k-step r of that channel group (k index = lane >> 5 = channel
+// parity, column = (frame, joint) = lane & 31).  The aggregation costs one 32-cycle MFMA per main k-step (shared
+// by nothing, so +25 % MFMA cycles at two column tiles per wave) and replaces every gather / DPP / VALU step:
+// any A, dense included, costs the same.  Where the operands live:
 //   * W (and the residual conv's Wr) in REGISTERS for the life of the persistent block: a wave owns one
-//     32-row M tile, so its A operand of (k, k-step s) is one register;
+//     32-row M tile, so its A operand of (k, k-step s) is one register; A_k's fragments are 12 registers;
 //   * the x tile arrives by LDS-DMA (global_load_lds_dwordx4: no VGPRs, no ds_write) into a double buffer,
 //     tile i+1 in flight while tile i is contracted - one barrier per tile, no exposed HBM latency.
 // Wave w: M tile w % MT, position group w / MT = 2*MT frames = MT column tiles of 2 frames x 16 joints.
 // RES: 0 none, 1 residual 1x1 conv at stride 1, 2 at stride 2 (MT == 2: the group's 2 even frames).
-template <int R>
-__device__ __forceinline__ float row_ror(float x) {
-    if (R == 0) return x;
-    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x120 + (R & 15), 0xF, 0xF, true));
-}
-
-template <int R, int END, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (R < END) {
-        f(std::integral_constant<int, R>{});
-        static_for<R + 1, END>(f);
-    }
-}
-
-// OCC blocks per CU: 2 where operands + accumulators fit 256 registers, else 1 (up to 512 with the AGPRs).
+// OCC blocks per CU (registers and LDS allow two at Ci = 32)
 template <int CIP, int MT, int RES>
-constexpr int gcn2_occ() { return (MT == 1 && (RES == 0 || CIP == 32)) ? 2 : 1; }
+constexpr int gcn2_occ() { return CIP == 32 ? 2 : 1; }   // Ci = 64: the two x images alone are 64 KiB of LDS
 
 template <int CIP, int MT, int RES>
 __global__ __launch_bounds__(256, (gcn2_occ<CIP, MT, RES>())) void gcn_fwd2_kernel(GcnParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int KS = CIP / 2;                          // k-steps (pairs of input channels)
     float* xs = smem;                                    // [2][CIP][128]
-    float* cfs = xs + 2 * CIP * GCN_P;                   // [3][16 rotations][16 joints]
-    float* colsum = cfs + 768;                           // [3][16]
+    float* colsum = xs + 2 * CIP * GCN_P;                // [3][16]
     float* bterm = colsum + 3 * 16;                      // [32*MT][16]
     float* brs = bterm + 32 * MT * 16;                   // [32*MT]
     float* stage = brs + 32 * MT;                        // [4 waves][32 rows][32*MT]: output transpose
@@ -382,21 +368,14 @@ __global__ __launch_bounds__(256, (gcn2_occ<CIP, MT, RES>())) void gcn_fwd2_kern
     };
     if ((int)blockIdx.x < p.ntiles) issue_dma(blockIdx.x, 0);
 
-    // ---- one-time per block: rotation coefficients, bias term, operands in registers -------------
-    // cf[k][R] = A[k][v = joint of the lane row_ror:R brings here][w = own joint]
-    unsigned rmask[3] = {0u, 0u, 0u};
-    static_for<0, 16>([&](auto rt) {
-        constexpr int R = decltype(rt)::value;
-        const int src = __float_as_int(row_ror<R>(__int_as_float(w16)));
+    // ---- one-time per block: adjacency fragments, bias term, operands in registers ----------------
+    // B operand of the aggregation MFMA: A_k[v = 4*c4 + (lane >> 4)][w = lane & 15]
+    float areg[3][4];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const float a = (k < p.K) ? p.A[(k * 16 + src) * 16 + w16] : 0.f;
-            if (tid < 16) cfs[(k * 16 + R) * 16 + w16] = a;
-            if (__ballot(a != 0.f) != 0ull) rmask[k] |= 1u << R;
-        }
-    });
+    for (int k = 0; k < 3; ++k)
 #pragma unroll
-    for (int k = 0; k < 3; ++k) rmask[k] = __builtin_amdgcn_readfirstlane(rmask[k]);
+        for (int c4 = 0; c4 < 4; ++c4)
+            areg[k][c4] = (k < p.K) ? p.A[(k * 16 + 4 * c4 + (lane >> 4)) * 16 + w16] : 0.f;
     if (tid < 48) {
         const int k = tid >> 4, w = tid & 15;
         float cs = 0.f;
@@ -456,7 +435,6 @@ __global__ __launch_bounds__(256, (gcn2_occ<CIP, MT, RES>())) void gcn_fwd2_kern
                 *reinterpret_cast<float4*>(out + (((size_t)n * p.Co + mt * 32 + ch) * Tout + tfirst) * 16 + lq * 4) = v;
         }
     };
-    const int crow = mt * 32 + 4 * half;                 // + (r&3) + 8*(r>>2): this lane's accumulator rows
     int buf = 0;
     for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
         const int n = tile / p.tiles_per_seq;
@@ -464,53 +442,70 @@ __global__ __launch_bounds__(256, (gcn2_occ<CIP, MT, RES>())) void gcn_fwd2_kern
         if (tile + (int)gridDim.x < p.ntiles) issue_dma(tile + gridDim.x, buf ^ 1);
         const float* xb = xs + buf * CIP * GCN_P;
 
-        f32x16 h[3][MT], ra[NRA];
+        f32x16 acc[MT], ra[NRA];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
 #pragma unroll
-            for (int k = 0; k < 3; ++k)
-#pragma unroll
-                for (int j = 0; j < MT; ++j) h[k][j][r] = 0.f;
+            for (int j = 0; j < MT; ++j) acc[j][r] = 0.f;
 #pragma unroll
             for (int j = 0; j < NRA; ++j) ra[j][r] = 0.f;
         }
-        const float* xlane = xb + half * GCN_P + frow * 16 + w16;          // + s*2*128 per k-step, + j*32 per column tile
+        // A operand of the aggregation MFMA (row i = lane & 15 of a 16-row z tile, k = lane >> 4): row
+        // i = 4q + r is (channel 2r + (q >> 1) of the 8-channel group, frame q & 1), k is the joint v
+        const float* xagg = xb + (2 * (lane & 3) + ((lane >> 3) & 1)) * GCN_P + (fbase + ((lane >> 2) & 1)) * 16 + (lane >> 4);
+        const float* xlane = xb + half * GCN_P + frow * 16 + w16;          // residual conv: B operand = x as it lies
         const float* xeven = xb + half * GCN_P + (fbase + 2 * (l31 >> 4)) * 16 + w16;   // RES == 2: the even frames
-        // B reads run one k-step ahead of the MFMAs; 3-4 MFMAs per read keep the stream MFMA-dense
-        float b[MT], be = 0.f;
 #pragma unroll
-        for (int j = 0; j < MT; ++j) b[j] = xlane[j * 32];
-        if constexpr (RES == 2) be = xeven[0];
-        __builtin_amdgcn_sched_barrier(0);
+        for (int g = 0; g < CIP / 8; ++g) {
+            // the x fragments of this 8-channel group: one per (column tile, 4-joint chunk), shared by the
+            // three partitions
+            float xa[MT][4];
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            float bn[MT], ben = 0.f;
-            if (s + 1 < KS) {
+            for (int j = 0; j < MT; ++j)
 #pragma unroll
-                for (int j = 0; j < MT; ++j) bn[j] = xlane[(s + 1) * 2 * GCN_P + j * 32];
-                if constexpr (RES == 2) ben = xeven[(s + 1) * 2 * GCN_P];
-            }
-#pragma unroll
-            for (int k = 0; k < 3; ++k)
-#pragma unroll
-                for (int j = 0; j < MT; ++j)
-                    h[k][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[k][s], b[j], h[k][j], 0, 0, 0);
+                for (int c4 = 0; c4 < 4; ++c4) xa[j][c4] = xagg[g * 8 * GCN_P + j * 32 + c4 * 4];
+            float xr[RES ? 4 : 1][NRA];
             if constexpr (RES == 1) {
 #pragma unroll
-                for (int j = 0; j < MT; ++j)
-                    ra[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wres[s], b[j], ra[j], 0, 0, 0);
-            } else if constexpr (RES == 2) {
-                ra[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wres[s], be, ra[0], 0, 0, 0);
-            }
-            if (s + 1 < KS) {
+                for (int r = 0; r < 4; ++r)
 #pragma unroll
-                for (int j = 0; j < MT; ++j) b[j] = bn[j];
-                be = ben;
+                    for (int j = 0; j < MT; ++j) xr[r][j] = xlane[(4 * g + r) * 2 * GCN_P + j * 32];
+            } else if constexpr (RES == 2) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xr[r][0] = xeven[(4 * g + r) * 2 * GCN_P];
             }
-            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                // z = x A_k for 8 channels x 2 frames on v_mfma_f32_16x16x4_f32; its 4 result registers ARE
+                // the B operands of the main product's k-steps 4g .. 4g+3 (lane = half*32 + frame*16 + joint)
+                f32x4 z[MT];
+#pragma unroll
+                for (int j = 0; j < MT; ++j) {
+                    z[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int c4 = 0; c4 < 4; ++c4)
+                        z[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[j][c4], areg[k][c4], z[j], 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int j = 0; j < MT; ++j)
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[k][4 * g + r], z[j][r], acc[j], 0, 0, 0);
+            }
+            if constexpr (RES == 1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int j = 0; j < MT; ++j)
+                        ra[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wres[4 * g + r], xr[r][j], ra[j], 0, 0, 0);
+            } else if constexpr (RES == 2) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    ra[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wres[4 * g + r], xr[r][0], ra[0], 0, 0, 0);
+            }
         }
 
-        // ---- aggregation over the joints of each frame (DPP rotations), bias term, store ----------------
+        // ---- bias term, store ------------------------------------------------------------------------
         // The next tile's DMA (issued before the k loop) is waited for HERE, before this tile's stores are
         // issued: __syncthreads() with an LDS-DMA in flight drains vmcnt(0), which at the end of the tile would
         // also wait for every store of the epilogue to reach L2 - several microseconds per tile at one wave per
@@ -523,28 +518,13 @@ __global__ __launch_bounds__(256, (gcn2_occ<CIP, MT, RES>())) void gcn_fwd2_kern
         // 1 KiB (64 / LPC channel rows of PW*4 contiguous bytes) instead of 256 B.
         float* stg = stage + wave * (32 * PW);
         {
-            float yv[MT][16];
 #pragma unroll
             for (int j = 0; j < MT; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) yv[j][r] = bterm[(crow + (r & 3) + 8 * (r >> 2)) * 16 + w16];
-            static_for<0, 3>([&](auto kt) {
-                constexpr int k = decltype(kt)::value;
-                static_for<0, 16>([&](auto rt) {
-                    constexpr int R = decltype(rt)::value;
-                    if ((rmask[k] >> R) & 1u) {
-                        const float c = cfs[(k * 16 + R) * 16 + w16];
-#pragma unroll
-                        for (int j = 0; j < MT; ++j)
-#pragma unroll
-                            for (int r = 0; r < 16; ++r) yv[j][r] = fmaf(c, row_ror<R>(h[k][j][r]), yv[j][r]);
-                    }
-                });
-            });
-#pragma unroll
-            for (int j = 0; j < MT; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) stg[((r & 3) + 8 * (r >> 2) + 4 * half) * PW + j * 32 + l31] = yv[j][r];
+                for (int r = 0; r < 16; ++r) {
+                    const int cl = (r & 3) + 8 * (r >> 2) + 4 * half;
+                    stg[cl * PW + j * 32 + l31] = acc[j][r] + bterm[(mt * 32 + cl) * 16 + w16];
+                }
             wide_store(stg, p.y, p.T, t0 + fbase, PW, (t0 + fbase + lq / 4) < p.T, n);
         }
 
@@ -585,7 +565,7 @@ __global__ __launch_bounds__(256, (gcn2_occ<CIP, MT, RES>())) void gcn_fwd2_kern
 
 template <int CIP, int MT, int RES>
 int launch_gcn2(const GcnParams& p, hipStream_t st) {
-    const size_t lds = ((size_t)2 * CIP * GCN_P + 768 + 3 * 16 + 32 * MT * 17 + 4 * 32 * 32 * MT) * 4;
+    const size_t lds = ((size_t)2 * CIP * GCN_P + 3 * 16 + 32 * MT * 17 + 4 * 32 * 32 * MT) * 4;
     auto kern = gcn_fwd2_kernel<CIP, MT, RES>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
