@@ -160,8 +160,16 @@ def time_hbm_kernels(n, t, device, reps=3):
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / reps
             gbs = 4.0 * nel / ms / 1e6
-            out.append({"kernel": "%s_b%d" % (name, bi), "bound": "hbm", "ms": round(ms, 3),
-                        "gbs": round(gbs, 1), "frac": round(gbs / PEAK_HBM_GBS, 4)})
+            row = {"kernel": "%s_b%d" % (name, bi), "bound": "hbm", "ms": round(ms, 3),
+                   "gbs": round(gbs, 1), "frac": round(gbs / PEAK_HBM_GBS, 4)}
+            if name.startswith("gcn") and ci >= 32:
+                # blocks 1-2: arithmetic intensity ~40 flop/B is above the fp32 ridge (~20), so the binding roofline
+                # is the fp32 MFMA peak; algorithmic FLOPs = 1x1 conv to K*Co channels + residual conv (x2 backward)
+                fl = (2.0 * 3 * ci * co * tt * 16 + (2.0 * ci * co * to * 16 if resconv else 0.0)) * n
+                fl *= 2.0 if name == "gcn_bwd" else 1.0
+                row.update({"bound": "mfma", "tflops": round(fl / ms / 1e9, 2),
+                            "frac": round(fl / ms / 1e9 / PEAK_FP32_MFMA_TFLOPS, 4), "frac_hbm": row["frac"]})
+            out.append(row)
         del x, y, dy, dx, r, dr, ws
     return out
 
