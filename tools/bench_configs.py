@@ -121,6 +121,33 @@ def config4(reps):
             "frac_fp32_mfma": n * fl / dt / PEAK_FP32}
 
 
+def cvae_train(reps):
+    """generator_cvae training iteration (utils/processor_stgcn.py:140-152): encoder -> reparametrisation ->
+    decoder -> between_frame_loss + KLD -> backward -> Adam; the reference logs ~16 s per iteration of batch 8
+    for this (its loss is an O(B T V C) Python loop)."""
+    from step_amd import losses
+    from step_amd.net.CVAE_stgcn import CVAE
+    torch.manual_seed(0)
+    m = CVAE(3, 75, 16, 32, 4, {"strategy": "spatial"}).to(D).train()
+    opt = torch.optim.Adam(m.parameters(), lr=0.1, weight_decay=1e-4)
+    n, t = 1024, 75
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn(n, 3, t, 16, 1, generator=g) * 0.5).to(D)
+    onehot = F.one_hot(torch.arange(n) % 4, 4).float().to(D)
+    lenc = onehot[:, :, None, None, None].repeat(1, 1, t, 16, 1)
+
+    def step():
+        rec, mean, lsig, _ = m(x, lenc, onehot)
+        loss = losses.vae_loss(x, rec, mean, lsig)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+    dt = timeit(step, reps)
+    fl = 3 * (stack_flops([(7, 64), (64, 32), (32, 32)], [1, 1, 1], t) + stack_flops([(32, 32), (32, 64), (64, 3)], [1, 1, 1], t))
+    return {"config": "CVAE train step (encoder + decoder fwd/bwd, between_frame_loss + KLD, Adam), batch 1024, T=75",
+            "gaits_per_s": n / dt, "ms": dt * 1e3, "gflop_per_gait_fwd_bwd": fl / 1e9, "frac_fp32_mfma": n * fl / dt / PEAK_FP32}
+
+
 def config5(reps):
     from step_amd.net.classifier_hybrid import Classifier
     torch.manual_seed(0)
@@ -193,7 +220,7 @@ def main():
     a = ap.parse_args()
     torch.cuda.set_device(D)
     for k in a.only.split(","):
-        r = {"2": config2, "3": config3, "4": config4, "5": config5, "aff": aff, "kt9": kt9}[k](a.reps)
+        r = {"2": config2, "3": config3, "4": config4, "5": config5, "aff": aff, "kt9": kt9, "cvae_train": cvae_train}[k](a.reps)
         for line in (r if isinstance(r, list) else [r]):
             print(json.dumps({k2: (round(v, 4) if isinstance(v, float) else v) for k2, v in line.items()}), flush=True)
 
