@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libstep_hip.so")
+LIB_PATH = os.environ.get("STEP_HIP_LIB") or os.path.join(_HERE, "lib", "libstep_hip.so")   # override: A/B builds
 
 P = ctypes.c_void_p
 I = ctypes.c_int
