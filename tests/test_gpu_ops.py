@@ -218,3 +218,32 @@ def test_bn_backward_tail_pair_equals_two_passes(N, C, T, training):
     got = ops.bn_backward_tail_pair(dout, out, u, r, m2, i2, w2, mr, ir, wr, training)
     for a, b_ in zip(got, tuple(ref_u) + tuple(ref_r)):
         assert torch.equal(a, b_)
+
+
+@pytest.mark.parametrize("strategy,Ci,Co,T", [("uniform", 32, 64, 19), ("distance", 64, 64, 9), ("distance", 3, 32, 12),
+                                               ("uniform", 64, 32, 24)])
+def test_gcn_other_graph_strategies(strategy, Ci, Co, T):
+    """Graph strategies 'uniform' (K = 1) and 'distance' (K = 2), net/utils/graph.py:71-82: fewer partitions than
+    the kernels' three slots"""
+    from step_amd.net.utils.tgcn import GcnFn
+    g = torch.Generator().manual_seed(8)
+    A = torch.tensor(graph_adjacency(strategy), dtype=torch.float32)
+    K = A.shape[0]
+    A = A * (torch.rand(K, 16, 16, generator=g) + 0.5)
+    x = torch.randn(2, Ci, T, 16, generator=g)
+    w = torch.randn(K * Co, Ci, 1, 1, generator=g) * 0.2
+    b = torch.randn(K * Co, generator=g)
+    leaves = [t.clone().requires_grad_(True) for t in (x, A, w, b)]
+    y = stgcn.conv_temporal_graphical(leaves[0], leaves[1], leaves[2], leaves[3], False)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    d = dev()
+    gl = [t.clone().to(d).requires_grad_(True) for t in (x, A, w, b)]
+    yg = GcnFn.apply(gl[0], gl[1], gl[2], gl[3], False, 16)
+    assert_close(yg, y, TOL, "gcn y")
+    yg.backward(gy.to(d))
+    assert_close(gl[0].grad, leaves[0].grad, TOL, "dx")
+    assert_close(gl[2].grad, leaves[2].grad, TOL, "dw")
+    assert_close(gl[3].grad, leaves[3].grad, TOL, "db")
+    supp = (A != 0).float()
+    assert_close(gl[1].grad.cpu() * supp, leaves[1].grad * supp, TOL, "dA on supp(A)")
