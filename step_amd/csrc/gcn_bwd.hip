@@ -349,11 +349,24 @@ __global__ __launch_bounds__(256, CIP <= 8 ? 2 : 1) void gcn_bwd_weight_kernel(G
     float* dys = smem;                               // [COPAD][PS]
     float* zk = dys + COPAD * PS;                    // [3][CIR][PS]; zk[0] doubles as the x tile
     float* czs = zk + 3 * CIR * PS;                  // [3][16 rotations][16 joints]
+    // MFMA aggregation (CIP >= 32): the x tile lies in LDS as [ci][PS]; at 32 channels in a region of its own,
+    // at 64 in the z_2 image (LDS is full), which is why the z fragments then wait in registers for a barrier
+    constexpr bool ZMFMA = CIP >= 32;
+    constexpr bool XT_OWN = CIP == 32;
+    float* xt = XT_OWN ? czs + 768 : zk + 2 * CIR * PS;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5, w16 = lane & 15;
     const int tile_id = wave % NTILE, ks = wave / NTILE;
     const int mt = tile_id / NCI, nt = tile_id % NCI;
+
+    // B operand of the aggregation MFMA (v_mfma_f32_16x16x4_f32): A_k[v = 4*c4 + (lane >> 4)][w = lane & 15]
+    float areg[3][4];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4)
+            areg[k][c4] = (ZMFMA && k < p.K) ? p.A[(k * 16 + 4 * c4 + (lane >> 4)) * 16 + w16] : 0.f;
 
     // column coefficients: cz[k][R] = A[k][v = joint of the lane row_ror:R brings][w = own joint]
     unsigned zmask[3] = {0u, 0u, 0u};
@@ -429,6 +442,55 @@ __global__ __launch_bounds__(256, CIP <= 8 ? 2 : 1) void gcn_bwd_weight_kernel(G
                     xr[i] = xr[i] * p.in_scale[w16 * p.Ci + ci] + p.in_shift[w16 * p.Ci + ci];
             }
         }
+        if constexpr (ZMFMA) {
+            // z_k = x A_k on the matrix cores: a 16-row z tile is 8 channels x 2 frames (row 4q + r = channel
+            // 2r + (q >> 1), frame q & 1), k = 4 joints per instruction; lane 16q + w of result register r holds
+            // z_k[channel 8g + 2r + (q >> 1)][frame 2fp + (q & 1)][w], written to the [ci][position] images the
+            // main product reads.  A wave takes every fourth (channel group, frame pair).
+            constexpr int NG = (CIP / 8) * 4 / 4;                 // groups per wave
+#pragma unroll
+            for (int i = 0; i < CPT; ++i) {
+                const int ci = (tid >> 7) + 2 * i;
+                if (ci < CIP) xt[ci * PS + pz] = xr[i];
+            }
+            __syncthreads();
+            const int ai = lane & 15;
+            const float* xa = xt + (2 * (ai & 3) + ((ai >> 3) & 1)) * PS + ((ai >> 2) & 1) * 16 + (lane >> 4);
+            const int zq = lane >> 4;
+            float* zw = zk + (zq >> 1) * PS + (zq & 1) * 16 + w16;
+            f32x4 zr[NG][3];
+#pragma unroll
+            for (int gi = 0; gi < NG; ++gi) {
+                const int grp = wave + 4 * gi, g = grp >> 2, fp = grp & 3;
+                float a4[4];
+#pragma unroll
+                for (int c4 = 0; c4 < 4; ++c4) a4[c4] = xa[8 * g * PS + fp * 32 + c4 * 4];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    zr[gi][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int c4 = 0; c4 < 4; ++c4)
+                        zr[gi][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[c4], areg[k][c4], zr[gi][k], 0, 0, 0);
+                }
+                if constexpr (XT_OWN) {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) zw[(k * CIR + 8 * g + 2 * r) * PS + fp * 32] = zr[gi][k][r];
+                }
+            }
+            if constexpr (!XT_OWN) {
+                __syncthreads();                                  // every wave has read the x tile out of z_2's image
+#pragma unroll
+                for (int gi = 0; gi < NG; ++gi) {
+                    const int grp = wave + 4 * gi, g = grp >> 2, fp = grp & 3;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) zw[(k * CIR + 8 * g + 2 * r) * PS + fp * 32] = zr[gi][k][r];
+                }
+            }
+        } else
         {
             // rotations outside, rows inside: one uniform branch per live (k, rotation) pair
             float z[3][CPT];
@@ -654,7 +716,7 @@ bool gb_geom(int N, int Ci, int Co, int T, int nnz, GbGeom* g) {
     g->cir = g->cip <= 32 ? 32 : 64;
     const int kqp = ((3 * g->cip + 31) / 32) * 32;
     g->lds1 = ((size_t)g->copad * kqp + (size_t)g->copad * P + (size_t)g->cip * P + 768) * 4;
-    g->lds2 = ((size_t)g->copad * PS + 3 * (size_t)g->cir * PS + 768) * 4;
+    g->lds2 = ((size_t)g->copad * PS + 3 * (size_t)g->cir * PS + 768 + (g->cip == 32 ? 32 * PS : 0)) * 4;
     if (g->lds2 < 4 * 64 * 64 * 4) g->lds2 = 4 * 64 * 64 * 4;       // the end-of-kernel wave reduction
     const long long ntiles = (long long)N * ((T + TT - 1) / TT);
     auto blocks = [&](size_t lds) {
