@@ -398,10 +398,22 @@ __global__ __launch_bounds__(256, CIP <= 8 ? 2 : 1) void gcn_bwd_weight_kernel(G
     // global -> registers for one tile (raw loads; issued a tile ahead so HBM latency hides under
     // the MFMA phase of the tile before)
     float xr[CPT];
-    float4 dyr[TT];
+    float4 dyr[TT], drr[TT];
     auto load_tile = [&](int tile) {
         const int n = tile / p.tiles_per_seq;
         const int t0 = (tile % p.tiles_per_seq) * TT;
+        if (p.dres) {                                    // the dres frames under this tile, a tile ahead as well
+            const int nfr = p.stride == 1 ? TT : TT / 2;
+            const int tr0 = t0 / p.stride;
+#pragma unroll
+            for (int t = 0; t < TT; ++t) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (t < nfr && cdy < p.Co && tr0 + t < p.To)
+                    v = *reinterpret_cast<const float4*>(
+                        p.dres + (((size_t)n * p.Co + cdy) * p.To + tr0 + t) * 16 + vq * 4);
+                drr[t] = v;
+            }
+        }
 #pragma unroll
         for (int t = 0; t < TT; ++t) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -421,7 +433,6 @@ __global__ __launch_bounds__(256, CIP <= 8 ? 2 : 1) void gcn_bwd_weight_kernel(G
 
     if ((int)blockIdx.x < p.ntiles) load_tile(blockIdx.x);
     for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
-        const int n = tile / p.tiles_per_seq;
         const int t0 = (tile % p.tiles_per_seq) * TT;
         const int next = tile + gridDim.x;
         __syncthreads();                                  // previous tile's MFMA reads are done
@@ -535,16 +546,6 @@ __global__ __launch_bounds__(256, CIP <= 8 ? 2 : 1) void gcn_bwd_weight_kernel(G
         if (p.dres) {
             // dWr[c,ci] += SUM_{t',w} dres[c,t',w] x[ci, s*t', w]: dres tile -> dys, x tile -> zk[0]
             const int nfr = p.stride == 1 ? TT : TT / 2;        // dres frames under this tile
-            const int tr0 = t0 / p.stride;
-            float4 drr[TT];
-#pragma unroll
-            for (int t = 0; t < TT; ++t) {
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (t < nfr && cdy < p.Co && tr0 + t < p.To)
-                    v = *reinterpret_cast<const float4*>(
-                        p.dres + (((size_t)n * p.Co + cdy) * p.To + tr0 + t) * 16 + vq * 4);
-                drr[t] = v;
-            }
             __syncthreads();
             if (cdy < COPAD) {
 #pragma unroll
