@@ -14,6 +14,7 @@
 // loads of chunk i+2 in flight across the barrier; exact fp32 bias sums on the way).  Slices of
 // the batch are combined by the ordered reduce of tcn_wgrad.hip (bit-reproducible).
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -36,21 +37,22 @@ struct WsCfg {
     static constexpr int NCONS = 4, NPROD = 4;
     static constexpr int NTHR = 64 * (NCONS + NPROD), PTHR = 64 * NPROD;
     static constexpr int TAPS = NCONS * NJ;                       // taps per block
-    static constexpr int AF = STRIDE * (TT - 1) + TAPS;           // activation frames per chunk
-    // row strides (bytes): an odd number of 16-byte chunks keeps the 16-byte row reads of 32
-    // channels on distinct bank groups
-    static constexpr int CHS = AF * 64 + 16;
+    static constexpr int AF = STRIDE * (TT - 1) + TAPS;           // activation frames a chunk reads
+    static constexpr int NEWF = STRIDE * TT;                      // ... of which only these are new
+    // The activation strip is a RING of frames in LDS: chunk c of a sequence reads slots [NEWF*c, NEWF*c + AF)
+    // (mod RING) while the NEWF frames of chunk c+1 land in the slots behind them, so RING >= AF + NEWF.  A frame
+    // is 2 KiB = [32 channels][4 quarters of 16 B] = two whole 1-KiB DMA pieces; quarter q of channel ch sits at
+    // position (q + (ch >> 2)) & 3 of its 64-byte row (the swizzle is applied to the per-lane SOURCE address),
+    // which puts the 16-byte reads of 16 consecutive channels on 16 distinct bank groups.
+    static constexpr int RING = (AF + NEWF <= 32) ? 32 : AF + NEWF;
+    static constexpr int FRAME_BYTES = 2048;
+    // dout rows: an odd number of 16-byte chunks keeps the 16-byte row reads of 32 channels on distinct bank groups
     static constexpr int DS = TT * 64 + 16;
     static constexpr int D_BYTES = (32 * MW * DS + 1023) / 1024 * 1024;   // whole 1-KiB DMA pieces
-    static constexpr int A_BYTES = (32 * CHS + 1023) / 1024 * 1024;           // whole 1-KiB DMA pieces
-    static constexpr int A_BASE = 2 * D_BYTES;                    // two images each
-    static constexpr int LDS_BYTES = A_BASE + 2 * A_BYTES;
-    static constexpr int D_ITEMS = 32 * MW * TT * 4;              // float4 items of the dout tile
-    static constexpr int A_ITEMS = 32 * AF * 4;
-    static constexpr int DN = D_ITEMS / PTHR;
-    static constexpr int AN = (A_ITEMS + PTHR - 1) / PTHR;
+    static constexpr int A_BASE = 2 * D_BYTES;                    // two dout images, then the ring
+    static constexpr int LDS_BYTES = A_BASE + RING * FRAME_BYTES;
     static constexpr int NBT = STRIDE * (TT - 1) + NJ;            // B fragments of one chunk (per wave)
-    static_assert(A_BYTES % 16 == 0 && LDS_BYTES <= 160 * 1024, "LDS");
+    static_assert(AF + NEWF <= RING && LDS_BYTES <= 160 * 1024, "LDS");
 };
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -144,35 +146,31 @@ __global__ __launch_bounds__(512) void tcn_wgrad_sw_kernel(WsParams p) {
             }
         };
 
-        // activation strip: the raw y frames go global -> LDS by DMA as well; tcn[0]/tcn[1] (BN +
-        // ReLU) are applied by the MFMA waves to the fragments they read (a lane of a B fragment is
-        // one input channel, so scale/shift are per-lane constants there), and frames outside the
-        // sequence are zeroed there too.  Chunk c of the image is (channel c / CPA, slot c % CPA);
-        // the per-lane source offsets do not depend on the chunk of the batch: computed once.
-        constexpr int CPA = C::CHS / 16;
-        constexpr int NPA = C::A_BYTES / 1024;
-        constexpr int APW = (NPA + C::NPROD - 1) / C::NPROD;
-        int arel[APW], afr[APW];
+        // activation strip: the raw y frames go global -> LDS by DMA as well, into the ring; tcn[0]/tcn[1] (BN +
+        // ReLU) are applied by the MFMA waves to the fragments they read (a lane of a B fragment is one input
+        // channel, so scale/shift are per-lane constants there), and frames outside the sequence are zeroed there
+        // too.  One piece = 16 channels of one frame: lane -> (channel, stored quarter); it fetches the source
+        // quarter that the swizzle maps there.
+        char* aring = smem + C::A_BASE;
+        const int pch = lane >> 2;                                  // channel within the piece
+        auto dma_frames = [&](auto count_tag, int n, int frame_first, int slot_first) {
+            constexpr int COUNT = decltype(count_tag)::value;
+            constexpr int PER = (2 * COUNT + C::NPROD - 1) / C::NPROD;
 #pragma unroll
-        for (int k = 0; k < APW; ++k) {
-            const int c = (k * C::NPROD + pwave) * 64 + lane;
-            const int cil = c / CPA, slot = c - cil * CPA;
-            const bool data = slot < CPA - 1 && cil < 32 && ci0 + cil < p.Ci;
-            afr[k] = data ? (slot >> 2) : -(1 << 28);
-            arel[k] = data ? (cil * p.Tin + (slot >> 2)) * 16 + (slot & 3) * 4 : 0;
-        }
-        auto dma_act = [&](int item, char* img) {
-            const int n = n0 + item / nchunks;
-            const int t0 = (item % nchunks) * TT;
-            const int row0 = STRIDE * t0 + j0 - p.pad;
-            const float* abase = p.in + ((size_t)n * p.Ci + ci0) * p.Tin * 16 + row0 * 16;
-#pragma unroll
-            for (int k = 0; k < APW; ++k) {
-                const int piece = k * C::NPROD + pwave;
-                if (piece < NPA) {
-                    const float* src = ((unsigned)(row0 + afr[k]) < (unsigned)p.Tin) ? abase + arel[k] : p.zeros;
+            for (int k0 = 0; k0 < PER; ++k0) {
+                const int k = k0 * C::NPROD + pwave;
+                if (k < 2 * COUNT) {
+                    const int fi = k >> 1, hp = k & 1;
+                    int slot = slot_first + fi;
+                    slot = slot >= C::RING ? slot - C::RING : slot;
+                    const int frame = frame_first + fi;
+                    const int ch = 16 * hp + pch;
+                    const int q = ((lane & 3) - (ch >> 2)) & 3;
+                    const float* src = ((unsigned)frame < (unsigned)p.Tin && ci0 + ch < p.Ci)
+                                           ? p.in + (((size_t)n * p.Ci + ci0 + ch) * p.Tin + frame) * 16 + q * 4
+                                           : p.zeros;
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                     (__attribute__((address_space(3))) void*)(img + piece * 1024),
+                                                     (__attribute__((address_space(3))) void*)(aring + slot * C::FRAME_BYTES + hp * 1024),
                                                      16, 0, 0);
                 }
             }
@@ -180,13 +178,23 @@ __global__ __launch_bounds__(512) void tcn_wgrad_sw_kernel(WsParams p) {
 
         const bool want_db = (qb % (p.ntb * p.ncib) == 0) && p.dbslab;     // one q-block per output group
         auto dbuf = [&](int item) { return smem + (item & 1) * C::D_BYTES; };
-        auto abuf = [&](int item) { return smem + C::A_BASE + (item & 1) * C::A_BYTES; };
-        if (total > 0) { dma_dout(0, dbuf(0)); dma_act(0, abuf(0)); }
-        __syncthreads();                       // (the compiler drains vmcnt before every barrier here)
         for (int it = 0; it < total; ++it) {
-            // the MFMA waves work on chunk `it`; chunk it+1 is requested into the other images and
-            // has the whole MFMA phase to land
-            if (it + 1 < total) { dma_dout(it + 1, dbuf(it + 1)); dma_act(it + 1, abuf(it + 1)); }
+            const int n = n0 + it / nchunks, c = it % nchunks;
+            if (c == 0) {
+                // sequence start: the whole strip, the ring restarts at slot 0 (the MFMA waves wait at the same
+                // barrier; once per sequence)
+                dma_frames(std::integral_constant<int, C::AF>{}, n, j0 - p.pad, 0);
+                if (it == 0) dma_dout(0, dbuf(0));
+                __syncthreads();                   // (the compiler drains vmcnt before every barrier here)
+            }
+            // the MFMA waves work on chunk `it`; the dout tile of chunk it+1 goes to the other image and, within a
+            // sequence, its NEWF new frames to the ring slots behind the ones being read
+            if (it + 1 < total) {
+                dma_dout(it + 1, dbuf(it + 1));
+                if (c + 1 < nchunks)
+                    dma_frames(std::integral_constant<int, C::NEWF>{}, n, STRIDE * TT * c + j0 - p.pad + C::AF,
+                               (C::NEWF * c + C::AF) % C::RING);
+            }
             if (want_db) sum_dout(dbuf(it));
             __syncthreads();
         }
@@ -212,21 +220,29 @@ __global__ __launch_bounds__(512) void tcn_wgrad_sw_kernel(WsParams p) {
             for (int r = 0; r < 16; ++r) acc[m][i][r] = 0.f;
 
     const int aoff = l31 * C::DS + half * 32;                                   // + mt*32*DS + tl*64
-    const int boff = l31 * C::CHS + (wave * NJ) * 64 + half * 32;               // + q*64
+    // ring reads: this lane's channel row of a frame slot, the two quarters 2*half and 2*half + 1 where the
+    // swizzle put them
+    const int boffa = l31 * 64 + (((2 * half) + (l31 >> 2)) & 3) * 16;
+    const int boffb = l31 * 64 + (((2 * half + 1) + (l31 >> 2)) & 3) * 16;
     float bsc = 1.f, bsh = 0.f;                       // tcn[0] of this lane's input channel
     if (p.in_scale && ci0 + l31 < p.Ci) { bsc = p.in_scale[ci0 + l31]; bsh = p.in_shift[ci0 + l31]; }
 
-    __syncthreads();
     for (int it = 0; it < total; ++it) {
+        const int cc = it % nchunks;
+        if (cc == 0) __syncthreads();                  // sequence start: the staging waves reload the whole strip
         const char* dimg = smem + (it & 1) * C::D_BYTES;
-        const char* aimg = smem + C::A_BASE + (it & 1) * C::A_BYTES;
+        const char* aring = smem + C::A_BASE;
+        int slot0 = (C::NEWF * cc) % C::RING + wave * NJ;         // ring slot of this wave's fragment 0
+        slot0 = slot0 >= C::RING ? slot0 - C::RING : slot0;
         auto read_a = [&](int mt, int tl) -> frag8 {
             const float4* q = reinterpret_cast<const float4*>(dimg + aoff + mt * 32 * C::DS + tl * 64);
             return frag8{q[0], q[1]};
         };
         auto read_b = [&](int qi) -> frag8 {
-            const float4* q = reinterpret_cast<const float4*>(aimg + boff + qi * 64);
-            return frag8{q[0], q[1]};
+            int slot = slot0 + qi;
+            slot = slot >= C::RING ? slot - C::RING : slot;
+            const char* fr = aring + slot * C::FRAME_BYTES;
+            return frag8{*reinterpret_cast<const float4*>(fr + boffa), *reinterpret_cast<const float4*>(fr + boffb)};
         };
         // tcn[0] scale/shift + tcn[1] ReLU on a fragment (this lane's channel); frames outside the
         // sequence are zero (the reference pads after the activation)
@@ -375,11 +391,11 @@ int step::wgrad_sw(const float* dout, const float* in, const float* in_scale, co
     p.Q = Ci * Kt; p.ntb = g.ntb; p.nqb = g.nqb; p.nsplit = g.nsplit; p.ncib = Ci / 32;
     int rc;
     if (bf16) {
-        if (g.mw == 1) rc = stride == 1 ? launch_ws<1, 5, 1, 6, true>(p, st) : launch_ws<1, 5, 2, 4, true>(p, st);
-        else rc = stride == 1 ? launch_ws<2, 5, 1, 6, true>(p, st) : launch_ws<2, 5, 2, 4, true>(p, st);
+        if (g.mw == 1) rc = stride == 1 ? launch_ws<1, 5, 1, 8, true>(p, st) : launch_ws<1, 5, 2, 6, true>(p, st);
+        else rc = stride == 1 ? launch_ws<2, 5, 1, 6, true>(p, st) : launch_ws<2, 5, 2, 6, true>(p, st);
     } else {
-        if (g.mw == 1) rc = stride == 1 ? launch_ws<1, 5, 1, 6, false>(p, st) : launch_ws<1, 5, 2, 4, false>(p, st);
-        else rc = stride == 1 ? launch_ws<2, 5, 1, 6, false>(p, st) : launch_ws<2, 5, 2, 4, false>(p, st);
+        if (g.mw == 1) rc = stride == 1 ? launch_ws<1, 5, 1, 8, false>(p, st) : launch_ws<1, 5, 2, 6, false>(p, st);
+        else rc = stride == 1 ? launch_ws<2, 5, 1, 6, false>(p, st) : launch_ws<2, 5, 2, 6, false>(p, st);
     }
     if (rc) return rc;
     return step::wgrad_reduce(p.slab, p.dbslab, dw, db, Co, Ci, Kt, g.nsplit, transposed, st,
