@@ -10,9 +10,11 @@
 // fragment of (frame t, tap j) depends only on s*t + j: an MFMA wave owns NJ consecutive taps and
 // slides a window along t, so one fragment read serves MW*NJ*8 = 80 MFMAs (tcn_wgrad.hip needs a
 // 4-byte LDS read per MFMA, which is what holds it at 0.73 of the MFMA peak).
-// Block = 4 MFMA waves + 4 staging waves (HBM -> registers -> BN + ReLU -> LDS, two images, the
-// loads of chunk i+2 in flight across the barrier; exact fp32 bias sums on the way).  Slices of
-// the batch are combined by the ordered reduce of tcn_wgrad.hip (bit-reproducible).
+// Block = 4 MFMA waves + 4 staging waves whose only work is LDS-DMA: the dout tile (two images) and the raw y
+// frames go global -> LDS with no VGPRs, and the MFMA waves apply BN + ReLU to the fragments they read.  The
+// activation strip is a ring of frames (see WsCfg): per chunk only the S*TT new frames are fetched, the whole
+// strip once per sequence.  Slices of the batch are combined by the ordered reduce of tcn_wgrad.hip
+// (bit-reproducible).
 #include "common.h"
 #include <type_traits>
 
