@@ -251,13 +251,26 @@ __global__ __launch_bounds__(512) void tcn_wgrad_sw_kernel(WsParams p) {
         const int t0c = (it % nchunks) * TT;
         const int frame0 = STRIDE * t0c + j0 - p.pad + wave * NJ;     // input frame of fragment 0
         auto activate = [&](frag8& f, int qi) {
+            // frames outside the sequence: scale = shift = 0 gives an exact zero with one select per fragment
+            // instead of one per element (the landed bytes there are the zero line, so 0 * x is 0, not NaN)
             const bool inside = (unsigned)(frame0 + qi) < (unsigned)p.Tin;      // wave-uniform
             float* v = reinterpret_cast<float*>(&f);
+            if constexpr (BF16) {
+                const float sc = inside ? bsc : 0.f, sh = inside ? bsh : 0.f;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float x = v[e] * bsc + bsh;
-                if (p.in_relu) x = fmaxf(x, 0.f);
-                v[e] = inside ? x : 0.f;
+                for (int e = 0; e < 8; ++e) {
+                    float x = v[e] * sc + sh;
+                    if (p.in_relu) x = fmaxf(x, 0.f);
+                    v[e] = x;
+                }
+            } else {
+                // (the fp32 mode is MFMA-bound and schedules better with the per-element select: measured)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float x = v[e] * bsc + bsh;
+                    if (p.in_relu) x = fmaxf(x, 0.f);
+                    v[e] = inside ? x : 0.f;
+                }
             }
         };
         frag8 a[TT][MW];
