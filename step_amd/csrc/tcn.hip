@@ -61,14 +61,16 @@ struct TcnCfg {
     static constexpr int WPIECES = WCHP / 256;                // 64 lanes x 16 B each
     static constexpr int WPW = (WPIECES + MW * NW - 1) / (MW * NW);   // pieces per wave
     static constexpr int BUF = STRIP + WCHP;
+    // two operand images; the epilogue re-uses them as wave-private output stages of 32 rows x 64 positions
+    static constexpr int SMEM = (2 * BUF > MW * NW * 2048) ? 2 * BUF : MW * NW * 2048;
     static_assert(STRIDE == 1 || ROWS % 2 == 0, "planes");
     static_assert(WCH % 4 == 0, "float4 weights");
 };
 
 template <int NT, int KS, int STRIDE, int MW, int NW>
-__global__ __launch_bounds__(64 * MW * NW, (2 * TcnCfg<NT, KS, STRIDE, MW, NW>::BUF * 4 > 80 * 1024) ? 1 : 2) void tcn_conv_kernel(TcnParams p) {
+__global__ __launch_bounds__(64 * MW * NW, (TcnCfg<NT, KS, STRIDE, MW, NW>::SMEM * 4 > 80 * 1024) ? 1 : 2) void tcn_conv_kernel(TcnParams p) {
     using Cfg = TcnCfg<NT, KS, STRIDE, MW, NW>;
-    __shared__ __attribute__((aligned(16))) float smem[2 * Cfg::BUF];
+    __shared__ __attribute__((aligned(16))) float smem[Cfg::SMEM];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -225,29 +227,51 @@ __global__ __launch_bounds__(64 * MW * NW, (2 * TcnCfg<NT, KS, STRIDE, MW, NW>::
     }
 
     if (!wave_live) return;
-    // epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    const int v = l31 & 15;
-    const int trow = l31 >> 4;
+    // epilogue.  C/D layout: col = lane&31 = (frame parity, joint), row = (r&3) + 8*(r>>2) + 4*(lane>>5) = channel,
+    // i.e. a lane holds ONE float of a 64-byte (channel, frame) row, and 4-byte global stores are issue-bound (a
+    // wave-instruction costs about the same whatever its width).  So two column tiles at a time go through a
+    // wave-private LDS stage [32 rows][64 positions] (the operand images are dead: the channel loop ended with a
+    // barrier) and come back as float4 along the frame axis: bias, tcn[3] affine, residual and ReLU are applied
+    // there, the residual is read 16 bytes wide as well, and one wave-instruction stores 1 KiB.
+    float* stg = smem + wave * 2048;
+    const int lch = lane >> 4, lq = lane & 15;
+    const int fp = lq >> 2, v0 = (lq & 3) * 4;            // frame of the pair of tiles, first joint
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int m = blockIdx.y * Cfg::MPAD + mw * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        const int ph = m / p.Cpad;
-        const int c = m - ph * p.Cpad;
-        if (c >= p.Cout || ph >= p.PH) continue;
-        const float bia = p.bias ? p.bias[c] : 0.f;
-        float osc = 1.f, osh = 0.f, rsc = 1.f, rsh = 0.f;
-        if (p.out_scale) { osc = p.out_scale[c]; osh = p.out_shift[c]; }
-        if (p.res && p.res_scale) { rsc = p.res_scale[c]; rsh = p.res_shift[c]; }
+    for (int i0 = 0; i0 < NT; i0 += 2) {
 #pragma unroll
-        for (int i = 0; i < NT; ++i) {
-            const int rho = rho0 + 2 * (wn * NT + i) + trow;
+        for (int jj = 0; jj < 2; ++jj)
+            if (i0 + jj < NT) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) stg[((r & 3) + 8 * (r >> 2) + 4 * half) * 64 + jj * 32 + l31] = acc[i0 + jj][r];
+            }
+        const int jt = fp >> 1;                               // column tile of this lane's frame
+        const int rho = rho0 + 2 * (wn * NT + i0 + jt) + (fp & 1);
+        const bool col_ok = (i0 + jt < NT) && rho < p.R;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int chl = k * 4 + lch;
+            const int m = blockIdx.y * Cfg::MPAD + mw * 32 + chl;
+            const int ph = m / p.Cpad;
+            const int c = m - ph * p.Cpad;
             const int t = p.PH * rho + ph;
-            if (rho < p.R && t < p.Tout) {
-                const size_t o = (((size_t)n * p.Cout + c) * p.Tout + t) * 16 + v;
-                float val = (acc[i][r] + bia) * osc + osh;
-                if (p.res) val += p.res[o] * rsc + rsh;
-                if (p.out_relu) val = fmaxf(val, 0.f);
-                p.out[o] = val;
+            if (col_ok && c < p.Cout && ph < p.PH && t < p.Tout) {
+                float4 v = *reinterpret_cast<const float4*>(stg + chl * 64 + lq * 4);
+                const float bia = p.bias ? p.bias[c] : 0.f;
+                float osc = 1.f, osh = 0.f;
+                if (p.out_scale) { osc = p.out_scale[c]; osh = p.out_shift[c]; }
+                v.x = (v.x + bia) * osc + osh; v.y = (v.y + bia) * osc + osh;
+                v.z = (v.z + bia) * osc + osh; v.w = (v.w + bia) * osc + osh;
+                const size_t o = (((size_t)n * p.Cout + c) * p.Tout + t) * 16 + v0;
+                if (p.res) {
+                    float rsc = 1.f, rsh = 0.f;
+                    if (p.res_scale) { rsc = p.res_scale[c]; rsh = p.res_shift[c]; }
+                    const float4 rv = *reinterpret_cast<const float4*>(p.res + o);
+                    v.x += rv.x * rsc + rsh; v.y += rv.y * rsc + rsh; v.z += rv.z * rsc + rsh; v.w += rv.w * rsc + rsh;
+                }
+                if (p.out_relu) {
+                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                }
+                *reinterpret_cast<float4*>(p.out + o) = v;
             }
         }
     }
