@@ -58,7 +58,8 @@ struct TbCfg {
     // of a transposing read (and the neighbouring frame's 4) over all 64 banks
     static constexpr int CHS = ((ROWS * 32 - 64 + 255) / 256) * 256 + 64;
     static constexpr int STRIP_BYTES = 16 * CHS;
-    static constexpr int LDS_BYTES = 2 * STRIP_BYTES;         // double-buffered
+    static constexpr int STAGE_BYTES = 4 * 32 * 32 * 4;       // output stages: one 32 x 32 tile per MFMA wave
+    static constexpr int LDS_BYTES = 2 * STRIP_BYTES + STAGE_BYTES;   // double-buffered strips + stages
     static constexpr int ITEMS = 16 * ROWS * 4;               // float4 items of one group
     static constexpr int SF4 = (ITEMS + PTHR - 1) / PTHR;
     static constexpr int NBTOT = STRIDE * 2 * (NT - 1) + KT2; // B fragments of one group
@@ -220,31 +221,44 @@ __global__ __launch_bounds__(64 * (MW * NW + NPROD)) void tcn_bf16_kernel(TbPara
             ++it;
         }
 
-        // epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+        // epilogue.  C/D layout: col = lane&31 = (frame parity, joint), row = (r&3) + 8*(r>>2) + 4*(lane>>5); a lane
+        // holds one float of a (channel, frame) row and 4-byte stores are issue-bound, so each column tile goes
+        // through this wave's LDS stage [32 rows][32 positions] and leaves (the residual arrives) as float4
         const int n = tile / p.nRB;
         const int rho0 = (tile % p.nRB) * Cfg::RB;
-        const int v = l31 & 15;
-        const int trow = l31 >> 4;
+        float* stg = reinterpret_cast<float*>(smem + 2 * Cfg::STRIP_BYTES) + wave * 1024;
+        const int lch = lane >> 3, lq = lane & 7;
+        const int fp = lq >> 2, v0 = (lq & 3) * 4;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = mw * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            const int ph = m / p.Cpad;
-            const int c = m - ph * p.Cpad;
-            if (c >= p.Cout || ph >= p.PH) continue;
-            const float bia = p.bias ? p.bias[c] : 0.f;
-            float osc = 1.f, osh = 0.f, rsc = 1.f, rsh = 0.f;
-            if (p.out_scale) { osc = p.out_scale[c]; osh = p.out_shift[c]; }
-            if (p.res && p.res_scale) { rsc = p.res_scale[c]; rsh = p.res_shift[c]; }
+        for (int i = 0; i < NT; ++i) {
 #pragma unroll
-            for (int i = 0; i < NT; ++i) {
-                const int rho = rho0 + 2 * (wn * NT + i) + trow;
+            for (int r = 0; r < 16; ++r) stg[((r & 3) + 8 * (r >> 2) + 4 * half) * 32 + l31] = acc[i][r];
+            const int rho = rho0 + 2 * (wn * NT + i) + fp;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int chl = k * 8 + lch;
+                const int m = mw * 32 + chl;
+                const int ph = m / p.Cpad;
+                const int c = m - ph * p.Cpad;
                 const int t = p.PH * rho + ph;
-                if (rho < p.R && t < p.Tout) {
-                    const size_t o = (((size_t)n * p.Cout + c) * p.Tout + t) * 16 + v;
-                    float val = (acc[i][r] + bia) * osc + osh;
-                    if (p.res) val += p.res[o] * rsc + rsh;
-                    if (p.out_relu) val = fmaxf(val, 0.f);
-                    p.out[o] = val;
+                if (c < p.Cout && ph < p.PH && rho < p.R && t < p.Tout) {
+                    float4 v = *reinterpret_cast<const float4*>(stg + chl * 32 + lq * 4);
+                    const float bia = p.bias ? p.bias[c] : 0.f;
+                    float osc = 1.f, osh = 0.f;
+                    if (p.out_scale) { osc = p.out_scale[c]; osh = p.out_shift[c]; }
+                    v.x = (v.x + bia) * osc + osh; v.y = (v.y + bia) * osc + osh;
+                    v.z = (v.z + bia) * osc + osh; v.w = (v.w + bia) * osc + osh;
+                    const size_t o = (((size_t)n * p.Cout + c) * p.Tout + t) * 16 + v0;
+                    if (p.res) {
+                        float rsc = 1.f, rsh = 0.f;
+                        if (p.res_scale) { rsc = p.res_scale[c]; rsh = p.res_shift[c]; }
+                        const float4 rv = *reinterpret_cast<const float4*>(p.res + o);
+                        v.x += rv.x * rsc + rsh; v.y += rv.y * rsc + rsh; v.z += rv.z * rsc + rsh; v.w += rv.w * rsc + rsh;
+                    }
+                    if (p.out_relu) {
+                        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                    }
+                    *reinterpret_cast<float4*>(p.out + o) = v;
                 }
             }
         }
