@@ -228,6 +228,40 @@ def test_full_size_properties():
     assert torch.allclose(full.sum(1).cpu(), torch.ones(512), atol=1e-5)
 
 
+@pytest.mark.parametrize("variant,N", [("real_only", 4096), ("real_and_synth", 512)])
+def test_full_size_train_step_replicated_batch(variant, N):
+    """The bench workloads' own shapes in train mode (configs[1]: real_only, N=4096 x 3 x 240 x 16; configs[2]:
+    real_and_synth, per-GPU batch 512): a batch made of N/8 copies of 8 gaits has the same batch statistics
+    (mean, biased variance), the same mean CrossEntropy and therefore the same parameter gradients as the 8
+    gaits alone, which the oracle does in seconds.  Exercises every kernel of the step with the full-size grids
+    against the oracle; also eval-mode batch-split invariance at that size."""
+    P = ckpt("ckpt_classifier_real_only_epoch395")
+    if variant == "real_and_synth":
+        d = sub(load_npz("real_and_synth_eval_T240"), "")
+        P = {k: v for k, v in P.items() if not k.startswith("st_gcn_networks.0.residual")}
+        P.update({k[2:]: v for k, v in d.items() if k.startswith("P.")})
+    g = torch.Generator().manual_seed(N)
+    x8 = torch.randn(8, 3, 240, 16, 1, generator=g) * 0.5
+    l8 = torch.arange(8) % 4
+    loss_ref, out_ref, grads = stgcn.classifier_loss_and_grads({k: v.clone() for k, v in P.items()}, x8, l8, variant)
+    m = _load(_variant_model(variant), P).train()
+    x = x8.repeat(N // 8, 1, 1, 1, 1).to(D)
+    out, _ = m(x)
+    loss = F.cross_entropy(out, l8.repeat(N // 8).to(D))
+    loss.backward()
+    assert abs(float(loss.detach()) - float(loss_ref)) < 2e-5
+    assert_close(out[:8], out_ref, 1e-4, "train-mode output")
+    assert torch.equal(out[:8], out[N - 8:])                      # copies are treated alike
+    for k, p in m.named_parameters():
+        assert_grad_close(p.grad, grads[k], 1e-3, k, 1e-5 if feeds_train_bn(k) else 1e-6)
+    m.eval()
+    with torch.no_grad():
+        xe = torch.randn(N, 3, 240, 16, 1, generator=g).to(D) * 0.5
+        full, _ = m(xe)
+        parts = torch.cat([m(xe[i:i + N // 4 - 24])[0] for i in range(0, N, N // 4 - 24)])
+    assert torch.equal(full, parts)
+
+
 @pytest.mark.parametrize("N,T,M", [(1, 37, 1), (3, 9, 1), (2, 101, 1), (2, 40, 2), (5, 75, 1)])
 def test_ragged_shapes_train_and_eval_vs_oracle(N, T, M):
     """Edge shapes: N == 1, T not a multiple of the 8/40-frame tiles, T odd under stride 2,
