@@ -367,9 +367,12 @@ extern "C" int step_tcn_conv(const float* in, const float* in_scale, const float
     }
     const int key = g.ks * 100 + g.stride_g * 10 + mw;
     hipStream_t st = (hipStream_t)stream;
+    // 128-row blocks cover 4*NT rho rows each: NT = 4 where that leaves fewer dead rows in the last block of a
+    // sequence than NT = 5 (R = 30: 32 instead of 40 rows of MFMA work), ties go to NT = 5 (one A read per 5 MFMAs)
+    const bool nt4 = step::ceil_div(p.R, 16) * 16 < step::ceil_div(p.R, 20) * 20;
     switch (key) {
-        case 3814: return launch_tcn<5, 38, 1, 4, 2>(p, st);
-        case 3824: return launch_tcn<5, 38, 2, 4, 2>(p, st);
+        case 3814: return nt4 ? launch_tcn<4, 38, 1, 4, 2>(p, st) : launch_tcn<5, 38, 1, 4, 2>(p, st);
+        case 3824: return nt4 ? launch_tcn<4, 38, 2, 4, 2>(p, st) : launch_tcn<5, 38, 2, 4, 2>(p, st);
         case 514: return launch_tcn<5, 5, 1, 4, 2>(p, st);
         case 524: return launch_tcn<5, 5, 2, 4, 2>(p, st);
         case 3811: return launch_tcn<5, 38, 1, 1, 4>(p, st);
@@ -377,7 +380,7 @@ extern "C" int step_tcn_conv(const float* in, const float* in_scale, const float
         case 3821: return launch_tcn<5, 38, 2, 1, 4>(p, st);
         case 3822: return launch_tcn<5, 38, 2, 2, 2>(p, st);
         case 1912: return launch_tcn<5, 19, 1, 2, 2>(p, st);
-        case 1914: return launch_tcn<5, 19, 1, 4, 2>(p, st);
+        case 1914: return nt4 ? launch_tcn<4, 19, 1, 4, 2>(p, st) : launch_tcn<5, 19, 1, 4, 2>(p, st);
         case 511: return launch_tcn<5, 5, 1, 1, 4>(p, st);
         case 512: return launch_tcn<5, 5, 1, 2, 2>(p, st);
         case 521: return launch_tcn<5, 5, 2, 1, 4>(p, st);
