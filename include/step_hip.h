@@ -59,6 +59,21 @@ int step_bn_train_prepare(const float* x, int N, int C, int T, int V, int bn_mod
                           float* mean, float* invstd, float* scale, float* shift,
                           void* ws, size_t ws_bytes, void* stream);
 
+/* step_bn_train_prepare for callers that cannot allocate (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc).  It has NO counterpart in the reference.  Same arguments, results and
+ * launches as step_bn_train_prepare (bit-identical outputs) minus the workspace: the chunk partials, totals
+ * and coefficients live in a file-scope device array of the library (1.06 MB per GPU, held until the process
+ * ends), whose address is looked up once per device on the first call there (the current device must be the
+ * stream's).  Limit: G = C (mode 0) or 16*C (mode 1) <= STEP_BN_STATIC_MAX_GROUPS, larger shapes are
+ * rejected with STEP_ERR_ARG.  Calls no hipMalloc / hipFree.  Every call on a GPU shares that GPU's array:
+ * calls that overlap on one GPU (two streams, two host threads) race - serialise them or use the
+ * workspace form.  Nothing in the array has to start at zero.                                          */
+#define STEP_BN_STATIC_MAX_GROUPS 256
+int step_bn_train_prepare_static(const float* x, int N, int C, int T, int V, int bn_mode,
+                                 const float* gamma, const float* beta,
+                                 float* running_mean, float* running_var, float momentum, float eps,
+                                 float* mean, float* invstd, float* scale, float* shift, void* stream);
+
 /* out = act( x*scale[g] + shift[g] + (res ? res*rscale[g] + rshift[g] : 0) ); rscale/rshift
  * NULL means identity.  The tail of st_gcn.forward: `self.relu(self.tcn(x) + res)`
  * classifier.py:189-191, and the Decoder's final data_bn CVAE_stgcn.py:224-229.            */

@@ -11,6 +11,7 @@
 // so results are bit-reproducible run to run.
 #include "common.h"
 #include <cstdlib>
+#include <mutex>
 
 namespace {
 
@@ -409,6 +410,61 @@ extern "C" int step_bn_train_prepare(const float* x, int N, int C, int T, int V,
                        gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale,
                        shift, G, count);
     return step::check_launch("step_bn_train_prepare");
+}
+
+// ---- the entry point that allocates nothing (no counterpart in the reference) ----------------------------
+// Same launches as step_bn_train_prepare with the workspace in a file-scope device array.  In host code the
+// array's NAME is only a stand-in: its device address is fetched once per device with hipGetSymbolAddress
+// (each GPU holds its own copy at its own address) and every launch below takes that pointer.
+constexpr int BN_STATIC_MAX_G = STEP_BN_STATIC_MAX_GROUPS;
+constexpr size_t BN_STATIC_BYTES =
+    ((size_t)BN_MAX_CHUNKS * BN_STATIC_MAX_G * 2 + 2 * (size_t)BN_STATIC_MAX_G) * 8 + 3 * (size_t)BN_STATIC_MAX_G * 4;
+static __device__ __align__(256) unsigned char scratch[BN_STATIC_BYTES];
+
+namespace {
+constexpr int MAX_DEVICES = 64;
+std::mutex g_scratch_mu;
+void* g_scratch_ptr[MAX_DEVICES] = {};
+
+// device address of `scratch` on the current device (looked up on the first call per device)
+int static_scratch(void** out) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess || dev < 0 || dev >= MAX_DEVICES) {
+        step::set_error("step_bn_train_prepare_static: hipGetDevice: %s (device %d)", hipGetErrorString(e), dev);
+        return STEP_ERR_LAUNCH;
+    }
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (!g_scratch_ptr[dev]) {
+        void* p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p) {
+            step::set_error("step_bn_train_prepare_static: hipGetSymbolAddress: %s", hipGetErrorString(e));
+            return STEP_ERR_LAUNCH;
+        }
+        g_scratch_ptr[dev] = p;
+    }
+    *out = g_scratch_ptr[dev];
+    return STEP_OK;
+}
+}  // namespace
+
+extern "C" int step_bn_train_prepare_static(const float* x, int N, int C, int T, int V, int bn_mode,
+                                            const float* gamma, const float* beta, float* running_mean,
+                                            float* running_var, float momentum, float eps, float* mean,
+                                            float* invstd, float* scale, float* shift, void* stream) {
+    BN_SHAPE_CHECK("step_bn_train_prepare_static");
+    const long long G = bn_mode ? 16LL * C : (long long)C;
+    STEP_REQUIRE(G <= BN_STATIC_MAX_G,
+                 "step_bn_train_prepare_static: %lld statistic groups exceed the static workspace's maximum of %d "
+                 "(use step_bn_train_prepare with a caller workspace)", G, BN_STATIC_MAX_G);
+    void* ws = nullptr;
+    const int rc = static_scratch(&ws);
+    if (rc != STEP_OK) return rc;
+    // every partial, total and coefficient the kernels read is written earlier in the same call: nothing in
+    // the array has to start at zero, so no memset is issued
+    return step_bn_train_prepare(x, N, C, T, V, bn_mode, gamma, beta, running_mean, running_var, momentum,
+                                 eps, mean, invstd, scale, shift, ws, ws_bytes((int)G), stream);
 }
 
 extern "C" int step_affine_act(const float* x, const float* scale, const float* shift,
