@@ -253,6 +253,14 @@ int step_vae_loss(const float* x_in, const float* x_out, const float* mean, cons
  * get_transformation (common.py:230-279, computed on the host), out (N,3,T,V).              */
 int step_pose_align(const float* gaits, const float* M, float* out, int N, int T, int V, void* stream);
 
+/* The same for a RAGGED set of gaits, fused with the padding of utils/loader.py:33-36: gait n is frames
+ * [offsets[n], offsets[n+1]) of `frames` (sum_len, V, 3); every gait is tiled to `time_steps` frames (the
+ * longest gait: np.tile(...)[0:time_steps]) and that block is repeated `cycles` times, so output frame t of
+ * gait n is source frame (t mod time_steps) mod len_n.  offsets: N+1 ints on the device, every gait at least
+ * one frame (checked by the host caller).  out (N, 3, time_steps*cycles, V).                       */
+int step_pose_align_ragged(const float* frames, const int* offsets, const float* M, float* out, int N,
+                           int time_steps, int cycles, int V, void* stream);
+
 /* ------------------------------------------------ affective features ----
  * feat[n, :] = compute_features(gaits[n], time_step, add_stride_features) of
  * compute_aff_features/compute_features.py:428-468 (helpers compute_aff_features/utils.py:3-34): box

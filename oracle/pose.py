@@ -50,3 +50,17 @@ def align_gaits(gaits):
         for k in range(T):
             out[s, k] = ((c * R) @ get_joints(gaits, s, k).T + t[:, None]).T.flatten()
     return out
+
+
+def assemble(data_list, cycles, joints=16, coords=3):
+    """utils/loader.py:33-37: gaits of different lengths, each (len_s, joints*coords), tiled to the longest
+    (``np.tile(...)[0:time_steps]``), that block repeated ``cycles`` times, then aligned -> (N, T*cycles, 48).
+    Pinned by tests/golden/assemble.npz (the reference's own lines run on ragged cuts of the shipped gaits)."""
+    time_steps = max(len(g) for g in data_list)
+    data = np.empty((len(data_list), time_steps * cycles, joints * coords))
+    for s, g in enumerate(data_list):
+        g = np.asarray(g)
+        idx = np.arange(time_steps) % len(g)
+        data[s] = np.concatenate([g[idx]] * cycles, 0)
+    padded = data.copy()
+    return align_gaits(data.reshape(len(data_list), -1, joints, coords)), padded

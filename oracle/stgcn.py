@@ -134,8 +134,39 @@ def temporal_conv(a, weight, bias, stride, transposed=False):
     return out if bias is None else out + bias.view(1, -1, 1, 1)
 
 
+def _rb(t):
+    """round to bf16 and back (round-to-nearest-even, what v_cvt_pk_bf16_f32 does)"""
+    return t.to(torch.bfloat16).to(t.dtype)
+
+
+class _TemporalConvBf16Operands(torch.autograd.Function):
+    """temporal_conv with its MFMA operands rounded to bf16 exactly where step_amd's bf16 kernels round
+    them (tcn_bf16.hip, tcn_wgrad_sw.hip BF16 mode; BASELINE config "real_and_synth training, bf16"):
+      forward : conv(bf16(a), bf16(w)) + b                  a = relu(bn1(y)) rounded on its way into LDS
+      dgrad   : conv_input_grad(bf16(w), bf16(dout))
+      wgrad   : conv_weight_grad(bf16(a), bf16(dout));  db = SUM dout (exact fp32)
+    Accumulation stays fp32.  This is what the model-level bf16 parity tests are held against (1e-3),
+    beside north_star's 1e-2 against the plain fp32 path."""
+
+    @staticmethod
+    def forward(ctx, a, weight, bias, stride):
+        ctx.save_for_backward(a, weight)
+        ctx.stride = stride
+        return temporal_conv(_rb(a), _rb(weight), bias, stride)
+
+    @staticmethod
+    def backward(ctx, dout):
+        a, weight = ctx.saved_tensors
+        ar = _rb(a).detach().requires_grad_(True)
+        wr = _rb(weight).detach().requires_grad_(True)
+        with torch.enable_grad():
+            out = temporal_conv(ar, wr, None, ctx.stride)
+        da, dw = torch.autograd.grad(out, (ar, wr), _rb(dout))
+        return da, dw, dout.sum(dim=(0, 2, 3)), None
+
+
 def st_gcn_block(x, A_eff, P, prefix, stride, residual, training,
-                 transposed=False, update_running=True, return_parts=False):
+                 transposed=False, update_running=True, return_parts=False, tcn_bf16=False):
     """st_gcn.forward classifier.py:185-191 / st_gctn.forward CVAE_stgcn.py:388-394."""
     gname = "gctn" if transposed else "gcn"
     has_res_conv = (prefix + ".residual.0.weight") in P
@@ -154,8 +185,11 @@ def st_gcn_block(x, A_eff, P, prefix, stride, residual, training,
     y = conv_temporal_graphical(x, A_eff, P[prefix + "." + gname + ".conv.weight"],
                                 P[prefix + "." + gname + ".conv.bias"], transposed)
     a = torch.relu(bn2d(y, P, prefix + ".tcn.0", training, update_running))
-    u = temporal_conv(a, P[prefix + ".tcn.2.weight"], P[prefix + ".tcn.2.bias"],
-                      stride, transposed)
+    if tcn_bf16 and not transposed:
+        u = _TemporalConvBf16Operands.apply(a, P[prefix + ".tcn.2.weight"], P[prefix + ".tcn.2.bias"], stride)
+    else:
+        u = temporal_conv(a, P[prefix + ".tcn.2.weight"], P[prefix + ".tcn.2.bias"],
+                          stride, transposed)
     v = bn2d(u, P, prefix + ".tcn.3", training, update_running)   # Dropout(p=0) is identity
     out = torch.relu(v if res is None else v + res)
     if return_parts:
@@ -164,18 +198,18 @@ def st_gcn_block(x, A_eff, P, prefix, stride, residual, training,
 
 
 def _stack(x, P, arch, net_prefix, imp_prefix, A, training, transposed=False,
-           update_running=True):
+           update_running=True, tcn_bf16=False):
     for i, (_, _, stride, residual) in enumerate(ARCH[arch]):
         key = "%s.%d" % (imp_prefix, i) if imp_prefix else None
         A_eff = A * P[key] if key is not None and key in P else A
         x = st_gcn_block(x, A_eff, P, "%s.%d" % (net_prefix, i), stride, residual,
-                         training, transposed, update_running)
+                         training, transposed, update_running, tcn_bf16=tcn_bf16)
     return x
 
 
 # ----------------------------------------------------------------- classifiers
 def classifier_forward(P, x, variant="real_only", training=False, x_aff=None,
-                       update_running=True):
+                       update_running=True, tcn_bf16=False):
     """x (N,C,T,V,M) with M == 1 (loader.py:65).  Returns (out, feature) for the
     two ST-GCN classifiers, logits only for the hybrid one."""
     n, c, t, v, m = x.shape
@@ -184,7 +218,7 @@ def classifier_forward(P, x, variant="real_only", training=False, x_aff=None,
     bn_name = "data_bn1" if variant == "hybrid" else "data_bn"
     h = data_bn(x4, P, bn_name, training, update_running)
     h = _stack(h, P, variant, "st_gcn_networks", "edge_importance", P["A"].to(x.dtype),
-               training, False, update_running)
+               training, False, update_running, tcn_bf16=tcn_bf16)
     pooled = h.mean(dim=(2, 3))                                  # avg_pool2d + mean over M
     if variant == "hybrid":
         z = torch.cat((pooled, x_aff), dim=1)
@@ -285,14 +319,14 @@ def trainable_keys(P):
             not k.endswith(("running_mean", "running_var", "num_batches_tracked"))]
 
 
-def classifier_loss_and_grads(P, x, labels, variant="real_only", x_aff=None):
+def classifier_loss_and_grads(P, x, labels, variant="real_only", x_aff=None, tcn_bf16=False):
     """One training-mode forward + backward: processor.py:322-327 (CrossEntropyLoss
     on the model output, which for real_only is already a softmax)."""
     keys = trainable_keys(P)
     leaves = {k: P[k].detach().clone().requires_grad_(True) for k in keys}
     Q = dict(P)
     Q.update(leaves)
-    out = classifier_forward(Q, x, variant, training=True, x_aff=x_aff)
+    out = classifier_forward(Q, x, variant, training=True, x_aff=x_aff, tcn_bf16=tcn_bf16)
     out = out if variant == "hybrid" else out[0]
     loss = F.cross_entropy(out, labels)
     grads = torch.autograd.grad(loss, [leaves[k] for k in keys])

@@ -47,6 +47,7 @@ SIGNATURES = {
     "step_vae_loss_ws_bytes": (Z, [I]),
     "step_vae_loss": (I, [P, P, P, P, F, P, P, P, P, I, I, I, I, I, P, Z, P]),
     "step_pose_align": (I, [P, P, P, I, I, I, P]),
+    "step_pose_align_ragged": (I, [P, P, P, P, I, I, I, I, P]),
     "step_aff_features": (I, [P, I, P, I, I, DBL, I, P]),
     "step_aff_normalize": (I, [P, P, I, I, I, P]),
     "step_pool_fwd": (I, [P, P, I, I, I, P]),
@@ -96,15 +97,34 @@ def _ptr(t):
     return t.data_ptr()
 
 
-def stream():
-    return torch.cuda.current_stream().cuda_stream
+def stream(device=None):
+    return torch.cuda.current_stream(device).cuda_stream
 
 
 def call(name, *args):
-    """Call an int-returning entry point on torch's current stream; raise on error."""
+    """Call an int-returning entry point on torch's current stream OF THE TENSORS' DEVICE; raise on error.
+    Every tensor argument must live on one GPU; the launch (and any per-device kernel attribute the library
+    sets) happens with that GPU current, whatever torch's current device is."""
     lib = load()
-    conv = [(_ptr(a) if (a is None or isinstance(a, torch.Tensor)) else a) for a in args]
-    rc = getattr(lib, name)(*conv, stream())
+    dev = None
+    conv = []
+    for a in args:
+        if a is None or isinstance(a, torch.Tensor):
+            conv.append(_ptr(a))
+            if a is not None:
+                if dev is None:
+                    dev = a.device
+                elif a.device != dev:
+                    raise StepHipError("%s: tensor arguments on different devices (%s and %s)"
+                                       % (name, dev, a.device))
+        else:
+            conv.append(a)
+    fn = getattr(lib, name)
+    if dev is None or dev.index == torch.cuda.current_device():
+        rc = fn(*conv, stream(dev))
+    else:
+        with torch.cuda.device(dev):
+            rc = fn(*conv, stream(dev))
     if rc != 0:
         raise StepHipError("%s failed (%d): %s" % (name, rc, lib.step_last_error().decode()))
 

@@ -117,18 +117,22 @@ __global__ __launch_bounds__(64) void bn_rows_fwd_kernel(const float* __restrict
     const int g = blockIdx.x, lane = threadIdx.x;
     float m, inv;
     if (training) {
-        float s = 0.f, ss = 0.f;
-        for (int n = lane; n < N; n += 64) { const float v = x[(size_t)n * G + g]; s += v; ss += v * v; }
-        s = wave_sum(s); ss = wave_sum(ss);
-        s = __shfl(s, 0, 64); ss = __shfl(ss, 0, 64);
-        m = s / N;
-        float var = ss / N - m * m;
-        var = var > 0.f ? var : 0.f;
-        inv = 1.f / sqrtf(var + eps);
+        // two passes in fp64 (mean, then SUM (x - mean)^2): a near-constant column such as 100 + 1e-2*randn
+        // would lose its variance to cancellation in a one-pass fp32 ss/N - m*m (N is small here)
+        double s = 0.0;
+        for (int n = lane; n < N; n += 64) s += (double)x[(size_t)n * G + g];
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        const double md = s / N;
+        double ss = 0.0;
+        for (int n = lane; n < N; n += 64) { const double d = (double)x[(size_t)n * G + g] - md; ss += d * d; }
+        for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+        const double vard = ss / N;
+        m = (float)md;
+        inv = (float)(1.0 / sqrt(vard + (double)eps));
         if (lane == 0 && running_mean) {
-            const float unb = N > 1 ? var * N / (N - 1) : var;
-            running_mean[g] = (1.f - momentum) * running_mean[g] + momentum * m;
-            running_var[g] = (1.f - momentum) * running_var[g] + momentum * unb;
+            const double unb = N > 1 ? vard * N / (N - 1) : vard;
+            running_mean[g] = (float)((1.0 - momentum) * running_mean[g] + momentum * md);
+            running_var[g] = (float)((1.0 - momentum) * running_var[g] + momentum * unb);
         }
     } else {
         m = running_mean[g];

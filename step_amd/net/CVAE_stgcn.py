@@ -36,6 +36,17 @@ class CVAE(nn.Module):
         return self.decoder(z, ldec, self.T, self.V)
 
 
+def _sync_nnz(module, blocks, attr):
+    """see _ClassifierBase._sync_nnz: the sparse kernels' bound follows the A buffer"""
+    key = (module.A.data_ptr(), module.A._version, module.A.device)
+    if getattr(module, "_nnz_key", None) != key:
+        nnz = a_nnz_max(module.A)
+        for b in blocks:
+            b.a_nnz_max = nnz
+            getattr(b, attr).a_nnz_max = nnz
+        module._nnz_key = key
+
+
 def _importance(module, blocks, flag):
     if flag:
         return nn.ParameterList([nn.Parameter(torch.ones(module.A.size())) for _ in blocks])
@@ -56,9 +67,7 @@ class Encoder(nn.Module):
             st_gcn(64, 32, kernel_size, 1, **kwargs),
             st_gcn(32, 32, kernel_size, 1, **kwargs),
         ))
-        nnz = a_nnz_max(A)
-        for b in self.encoder:
-            b.a_nnz_max = b.gcn.a_nnz_max = nnz
+        _sync_nnz(self, self.encoder, "gcn")
         self.edge_importance = _importance(self, self.encoder, edge_importance_weighting)
         self.z_mean = nn.Conv2d(32, n_z, kernel_size=1)
         self.z_lsig = nn.Conv2d(32, n_z, kernel_size=1)
@@ -69,6 +78,7 @@ class Encoder(nn.Module):
         N, C, T, V, M = x.size()
         assert M == 1, "the reference only ever feeds M == 1"
         h = x.reshape(N, C, T, V).float().contiguous()
+        _sync_nnz(self, self.encoder, "gcn")
         for i, (gcn, importance) in enumerate(zip(self.encoder, self.edge_importance)):
             h, _ = gcn(h, self.A * importance, self.data_bn if i == 0 else None)
         pooled = PoolFn.apply(h)
@@ -91,9 +101,7 @@ class Decoder(nn.Module):
             st_gctn(32, 64, kernel_size, 1, **kwargs),
             st_gctn(64, in_channels, kernel_size, 1, **kwargs),
         ))
-        nnz = a_nnz_max(A)
-        for b in self.decoder:
-            b.a_nnz_max = b.gctn.a_nnz_max = nnz
+        _sync_nnz(self, self.decoder, "gctn")
         self.edge_importance = _importance(self, self.decoder, edge_importance_weighting)
         self.data_bn = nn.BatchNorm1d(in_channels * A.size(1))
         self.out = nn.Sigmoid()          # constructed but unused, as in the reference (:196,230)
@@ -104,6 +112,7 @@ class Decoder(nn.Module):
         zl = torch.cat((z, l), dim=1).float().contiguous()
         h = DenseFn.apply(zl, self.fcn.weight, self.fcn.bias, True)         # (N, 32)
         h = h[:, :, None, None].expand(N, h.size(1), T, V).contiguous()     # z.repeat([1,1,T,V])
+        _sync_nnz(self, self.decoder, "gctn")
         for gcn, importance in zip(self.decoder, self.edge_importance):
             h, _ = gcn(h, self.A * importance)
         h = DataBnFn.apply(self.data_bn, self.training, h, self.data_bn.weight, self.data_bn.bias)

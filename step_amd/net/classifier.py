@@ -30,15 +30,24 @@ class _ClassifierBase(nn.Module):
             blocks.append(st_gcn(cin, cout, kernel_size, stride, **kw))
             cin = cout
         self.st_gcn_networks = nn.ModuleList(blocks)
-        nnz = a_nnz_max(A)
-        for b in self.st_gcn_networks:
-            b.a_nnz_max = nnz
-            b.gcn.a_nnz_max = nnz
+        self._sync_nnz()
         if edge_importance_weighting:
             self.edge_importance = nn.ParameterList(
                 [nn.Parameter(torch.ones(self.A.size())) for _ in self.st_gcn_networks])
         else:
             self.edge_importance = [1] * len(self.st_gcn_networks)
+
+    def _sync_nnz(self):
+        """The EMAX = 4 sparse variants of the graph-conv kernels drop entries beyond ``a_nnz_max`` per
+        column / row, so the bound follows the A buffer: recomputed whenever A was written
+        (load_state_dict, .to(), in-place edits bump ``_version``; a new tensor has a new data_ptr)."""
+        key = (self.A.data_ptr(), self.A._version, self.A.device)
+        if getattr(self, "_nnz_key", None) != key:
+            nnz = a_nnz_max(self.A)
+            for b in self.st_gcn_networks:
+                b.a_nnz_max = nnz
+                b.gcn.a_nnz_max = nnz
+            self._nnz_key = key
 
     def _stack(self, x):
         N, C, T, V, M = x.size()
@@ -51,6 +60,7 @@ class _ClassifierBase(nn.Module):
             raise _lib.StepHipError("step_amd models run on the GPU only (input is on %s)" % x.device)
         x = x.float().contiguous()
         data_bn = getattr(self, self.DATA_BN)
+        self._sync_nnz()
         for i, (gcn, importance) in enumerate(zip(self.st_gcn_networks, self.edge_importance)):
             x, _ = gcn(x, self.A * importance, data_bn if i == 0 else None)
         return x, (N, M)

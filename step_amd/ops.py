@@ -212,6 +212,11 @@ class StGcnBlockFn(torch.autograd.Function):
         Co, Kt, st = s.Co, s.Kt, s.stride
         To = (T - 1) // st + 1
         K = A_eff.shape[0]
+        if s.data_bn is not None and s.residual == "identity":
+            # the reference's identity residual adds the NORMALISED input (data_bn runs first,
+            # classifier.py:68-78); with data_bn folded into the graph-conv load only the raw x exists
+            raise _lib.StepHipError("a first block with an identity residual (in == out channels, stride 1) "
+                                    "behind a folded data_bn is not supported")
         need_grad = any(ctx.needs_input_grad)       # all False under torch.no_grad()
         dev = x.device
 

@@ -57,3 +57,31 @@ def align_gaits(gaits, device="cuda:0", transforms=None):
     out = torch.empty((N, 3, T, V), dtype=torch.float32, device=g_dev.device)
     _lib.call("step_pose_align", g_dev, M_dev, out, N, T, V)
     return out.unsqueeze(-1)
+
+
+def assemble(data_list, cycles=3, joints=16, coords=3, device="cuda:0"):
+    """``load_data`` of utils/loader.py between the HDF5 read and the train/test split (:33-37): a list of
+    variable-length gaits, each (len_s, joints*coords), becomes the aligned model input
+    (N, 3, time_steps*cycles, 16, 1), time_steps = the longest gait.  The reference tiles every gait to
+    time_steps frames with ``np.tile``, writes that block ``cycles`` times into a dense (N, T, 48) array and
+    then aligns it; here only the ragged frames go to the GPU and ONE launch indexes the source frame
+    ``(t mod time_steps) mod len_s`` while it aligns and re-lays out (``step_pose_align_ragged``).
+    Returns (x, time_steps)."""
+    if coords != 3:
+        raise _lib.StepHipError("assemble: the alignment is 3-D (coords must be 3, got %d)" % coords)
+    gaits = [np.asarray(g, dtype=np.float64).reshape(-1, joints, coords) for g in data_list]
+    if not gaits or any(g.shape[0] < 1 for g in gaits):
+        raise _lib.StepHipError("assemble: every gait needs at least one frame")
+    lens = np.asarray([g.shape[0] for g in gaits], dtype=np.int64)
+    time_steps = int(lens.max())
+    N = len(gaits)
+    if int(lens.sum()) >= 2 ** 31:
+        raise _lib.StepHipError("assemble: more than 2^31 frames")
+    first = np.stack([g[0] for g in gaits])[:, None]                     # (N, 1, V, 3): all the transforms need
+    M = similarity_transforms(first)
+    frames = torch.as_tensor(np.concatenate(gaits, 0), dtype=torch.float32).contiguous().to(device)
+    off = torch.as_tensor(np.concatenate([[0], np.cumsum(lens)]), dtype=torch.int32).to(device)
+    M_dev = torch.as_tensor(M, dtype=torch.float32).contiguous().to(device)
+    out = torch.empty((N, 3, time_steps * cycles, joints), dtype=torch.float32, device=frames.device)
+    _lib.call("step_pose_align_ragged", frames, off, M_dev, out, N, time_steps, cycles, joints)
+    return out.unsqueeze(-1), time_steps

@@ -473,6 +473,107 @@ def gen_pose_align():
     save("pose_align", **out)
 
 
+# --------------------------------------------------------------------------- 10b
+def gen_assemble():
+    """SURVEY 8(f)3, utils/loader.py:21-37: the pad / tile / `cycles` assembly of load_data followed by the
+    alignment.  loader.py itself cannot be imported here (h5py, torchvision are absent), so the statements of
+    load_data between the HDF5 opens and train_test_split are read from the reference file at generation time
+    and executed as they stand, with plain dicts of numpy arrays standing in for the two h5py.File objects
+    (they only need .keys(), item access, len() and [()]).  Nothing of the source is stored: the fixture holds
+    the ragged inputs and the reference's outputs."""
+    for k in list(sys.modules):
+        if k == "utils" or k.startswith("utils."):
+            del sys.modules[k]
+    sys.path[:] = [q for q in sys.path if not q.startswith(REF)]
+    sys.path.insert(0, os.path.join(REF, "classifier_stgcn_real_only"))
+    common = importlib.import_module("utils.common")
+    src = open(os.path.join(REF, "classifier_stgcn_real_only", "utils", "loader.py")).read().splitlines()
+    start = next(i for i, l in enumerate(src) if l.strip().startswith("data_list = []"))
+    pad_end = next(i for i, l in enumerate(src) if "common.get_affective_features" in l)
+    import textwrap
+    part1 = textwrap.dedent("\n".join(src[start:pad_end]))          # read loop + pad/tile/cycle
+    part2 = textwrap.dedent(src[pad_end])                             # the alignment line
+    names, feats, labels = load_h5_gaits()                           # (60, 18, 48) f64
+    rng = np.random.default_rng(77)
+    out = {}
+    for tag, (n, cycles) in {"c3": (60, 3), "c1": (7, 1)}.items():
+        lens = rng.integers(5, 19, n)
+        lens[0] = 18 if tag == "c3" else 11                          # the longest gait need not be 18
+        lens[1] = 1 if tag == "c1" else lens[1]                      # a one-frame gait
+        ff = {names[i]: feats[i, :lens[i]].copy() for i in range(n)}
+        fl = {names[i]: np.asarray(labels[i]) for i in range(n)}
+        ns = dict(np=np, common=common, ff=ff, fl=fl, cycles=cycles, joints=16, coords=3)
+        exec(part1, ns)
+        out[tag + ".padded"] = ns["data"].copy()
+        exec(part2, ns)
+        out[tag + ".aligned"] = ns["data"].copy()
+        out[tag + ".lens"] = lens.astype(np.int64)
+        out[tag + ".frames"] = np.concatenate([ff[k] for k in ff], 0)
+        out[tag + ".labels"] = ns["labels"].copy()
+        out[tag + ".cycles"] = np.int64(cycles)
+        assert ns["data"].shape == (n, int(lens.max()) * cycles, 48)
+    save("assemble", **out)
+
+
+# --------------------------------------------------------------------------- 6b
+def gen_trajectory():
+    """processor.py:316-335 over several iterations: 5 steps of Adam(lr=0.1, wd=1e-4) (processor.py:251-255) on
+    the real_only Classifier, Kt = 75, N = 8, T = 75, with the LR dropped x0.1 before step 4 (adjust_lr,
+    processor.py:260-268).  Stores the loss of every step, the final state_dict (incl. num_batches_tracked and
+    the BN running statistics) and the initial parameters."""
+    cl = ref_import("classifier_stgcn_real_only", "classifier")
+    torch.manual_seed(21)
+    model = cl.Classifier(3, 4, {"strategy": "spatial"})
+    _init_like_processor(model)
+    n, t = 8, 75
+    xs = torch.randn(5, n, 3, t, 16, 1) * 0.5
+    labels = torch.randint(0, 4, (5, n))
+    P0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+
+    def run(dtype, jitter=None):
+        m = cl.Classifier(3, 4, {"strategy": "spatial"})
+        m.load_state_dict(P0)
+        m = m.to(dtype)
+        opt = torch.optim.Adam(m.parameters(), lr=0.1, weight_decay=1e-4)
+        lossf = torch.nn.CrossEntropyLoss()
+        losses, outs = [], []
+        m.train()
+        for it in range(5):
+            if it == 3:
+                for g in opt.param_groups:
+                    g["lr"] = 0.01
+            xin = xs[it] if jitter is None else xs[it] * (1.0 + 1e-7 * torch.randn(xs[it].shape, generator=jitter))
+            o, _ = m(xin.to(dtype))
+            loss = lossf(o, labels[it])
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            losses.append(loss.item())
+            outs.append(o.detach().float().numpy().copy())
+        return m, losses, outs
+
+    model, losses, outs = run(torch.float32)
+    m64, losses64, _ = run(torch.float64)
+    out = dict(x=xs.numpy(), labels=labels.numpy(), losses=np.asarray(losses, dtype=np.float64),
+               losses_f64=np.asarray(losses64, dtype=np.float64), outs=np.stack(outs))
+    out.update(flat("P0.", npd(P0)))
+    P5, P5d = npd(model.state_dict()), npd(m64.state_dict())
+    out.update(flat("P5.", P5))
+    # how far the reference's OWN fp32 run is from its float64 run, per tensor: Adam divides by sqrt(v), so a
+    # parameter whose true gradient is zero (conv biases in front of a train-mode BN) or at round-off level takes
+    # +-lr steps along the SIGN of rounding noise - its fp32 trajectory is not reproducible by any implementation.
+    # Tests allow that much on top of their own tolerance.
+    # ... and from four fp32 runs whose inputs are moved by one part in 10^7 (less than an fp32 ulp of most values)
+    others = [P5d]
+    for seed in range(4):
+        mj, _, _ = run(torch.float32, torch.Generator().manual_seed(100 + seed))
+        others.append(npd(mj.state_dict()))
+    for k in P5:
+        if P5[k].dtype.kind == "f":
+            out["noise." + k] = np.float64(max(np.abs(P5[k].astype(np.float64) - o[k]).max() for o in others))
+    save("trajectory", **out)
+
+
 # --------------------------------------------------------------------------- 11
 def gen_affective():
     """compute_aff_features/compute_features.py:428-468 (27 posture/movement features per
@@ -511,9 +612,9 @@ def gen_affective():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["graph", "gcn", "blocks", "ckpt", "train", "cvae", "hybrid", "vae_loss", "pose", "affective"]
+    which = sys.argv[1:] or ["graph", "gcn", "blocks", "ckpt", "train", "cvae", "hybrid", "vae_loss", "pose", "affective", "assemble", "trajectory"]
     fns = dict(graph=gen_graph, gcn=gen_gcn, blocks=gen_blocks, ckpt=gen_ckpt_and_eval,
                train=gen_train_steps, cvae=gen_cvae, hybrid=gen_hybrid, vae_loss=gen_vae_loss, pose=gen_pose_align,
-               affective=gen_affective)
+               affective=gen_affective, assemble=gen_assemble, trajectory=gen_trajectory)
     for w in which:
         fns[w]()

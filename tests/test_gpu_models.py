@@ -6,7 +6,7 @@ import torch.nn.functional as F
 
 from oracle import stgcn
 from tests.util import load_npz, sub, ckpt, assert_close, assert_grad_close, feeds_train_bn, grad_noise
-from tests.test_oracle_golden import _block_cases, block_meta
+from tests.test_oracle_golden import _block_cases, block_meta, trajectory_state_check
 
 pytestmark = pytest.mark.gpu
 D = "cuda:0"
@@ -337,3 +337,95 @@ def test_batched_prediction_and_feature_export():
     assert feats.shape == (N, 64) and len(by_key) == N and by_key["gait007"].shape == (64,)
     one, _ = export.generate_predictions(m, raw[:3], 4, 16, 3, batch=1)    # the reference's own batching
     assert np.array_equal(one, labels[:3])
+
+
+def test_five_step_trajectory_vs_reference():
+    """processor.py:316-335 over several iterations: 5 x (forward, CrossEntropyLoss, backward, Adam.step) on the
+    real_only Classifier (Kt = 75, N = 8, T = 75), lr 0.1 dropped to 0.01 before the 4th step (adjust_lr,
+    processor.py:260-268).  Weights are re-packed from the updated parameters every step; loss and train-mode
+    output of EVERY step, the final state_dict, the BN running statistics and num_batches_tracked are held
+    against the reference's run."""
+    d = sub(load_npz("trajectory"), "")
+    m = _variant_model("real_only")
+    m.load_state_dict({k[3:]: v for k, v in d.items() if k.startswith("P0.")})
+    m = m.to(D).train()
+    opt = torch.optim.Adam(m.parameters(), lr=0.1, weight_decay=1e-4)
+    lossf = torch.nn.CrossEntropyLoss()
+    for it in range(5):
+        if it == 3:
+            for g in opt.param_groups:
+                g["lr"] = 0.01
+        out, _ = m(d["x"][it].to(D))
+        loss = lossf(out, d["labels"][it].to(D))
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        assert abs(float(loss.detach()) - float(d["losses"][it])) <= 1e-5 * max(1.0, abs(float(d["losses"][it]))), it
+        assert_close(out, d["outs"][it], 1e-4, "train-mode output of step %d" % it)
+    assert trajectory_state_check(m.state_dict(), d) >= 55
+
+
+def test_dense_A_loaded_into_a_sparse_graph_model():
+    """The sparse (EMAX = 4) graph-conv kernels are selected from the A buffer's non-zero count; a checkpoint may
+    overwrite A (it is a persistent buffer).  A dense A loaded into a model built with the sparse skeleton must
+    give the oracle's numbers in every block, forward and backward."""
+    P = ckpt("ckpt_classifier_real_only_epoch395")
+    g = torch.Generator().manual_seed(17)
+    P = dict(P, A=torch.rand(3, 16, 16, generator=g) * 0.2)
+    x = torch.randn(4, 3, 40, 16, 1, generator=g) * 0.5
+    labels = torch.arange(4) % 4
+    loss_ref, out_ref, grads = stgcn.classifier_loss_and_grads({k: v.clone() for k, v in P.items()}, x, labels, "real_only")
+    m = _variant_model("real_only")
+    assert m.st_gcn_networks[0].a_nnz_max < 16
+    m.load_state_dict(P)
+    m = m.to(D).train()
+    out, _ = m(x.to(D))
+    assert m.st_gcn_networks[0].a_nnz_max == 16 and m.st_gcn_networks[2].gcn.a_nnz_max == 16
+    F.cross_entropy(out, labels.to(D)).backward()
+    assert_close(out, out_ref, 1e-4, "output with a dense A")
+    for k, p in m.named_parameters():
+        assert_grad_close(p.grad, grads[k], 1e-3, k, 2e-6 if feeds_train_bn(k) else 2e-7)
+
+
+def test_first_block_identity_residual_behind_data_bn_is_refused():
+    """ops.StGcnBlockFn: with data_bn folded into the graph-conv load, an identity residual would add the raw x
+    where the reference adds the normalised x (classifier.py:68-78,170-171) - refused, not silently wrong"""
+    from step_amd._lib import StepHipError
+    from step_amd.net.classifier import Classifier
+    m = Classifier(32, 4, {"strategy": "spatial"}).to(D)         # 32 -> 32, stride 1: identity residual in block 0
+    with pytest.raises(StepHipError, match="identity residual"):
+        m(torch.zeros(2, 32, 20, 16, 1, device=D))
+
+
+def test_bn_rows_near_constant_column():
+    """hybrid head's data_bn2 (classifier_hybrid/net/classifier.py:46,83): a column such as 100 + 1e-2 * randn must
+    keep its variance (two-pass fp64 statistics), checked against torch's BatchNorm1d in float64"""
+    from step_amd.ops import BnRowsFn
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(256, 7, generator=g)
+    x[:, 2] = 100.0 + 1e-2 * torch.randn(256, generator=g)
+    x[:, 5] = -3000.0 + 1e-1 * torch.randn(256, generator=g)
+    bn = torch.nn.BatchNorm1d(7).to(D).train()
+    ref_bn = torch.nn.BatchNorm1d(7).double().train()
+    y = BnRowsFn.apply(bn, True, x.to(D), bn.weight, bn.bias)
+    ref = ref_bn(x.double())
+    assert float((y.cpu().double() - ref).abs().max()) < 2e-3      # fp32 inputs near 100 carry ~1e-5/1e-2 relative
+    assert_close(bn.running_var, ref_bn.running_var, 1e-5, "running_var")
+    assert_close(bn.running_mean, ref_bn.running_mean, 1e-6, "running_mean")
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs")
+def test_second_gpu_without_set_device():
+    """_lib.call launches on the tensors' device and stream, not on torch's current device"""
+    from step_amd._lib import StepHipError
+    P = ckpt("ckpt_classifier_real_only_epoch395")
+    m = _load(_variant_model("real_only"), P).eval()
+    x = torch.randn(3, 3, 30, 16, 1) * 0.5
+    with torch.no_grad():
+        a, _ = m(x.to(D))
+        m1 = m.to("cuda:1")
+        assert torch.cuda.current_device() == 0
+        b, _ = m1(x.to("cuda:1"))
+        assert torch.equal(a.cpu(), b.cpu())
+        with pytest.raises(StepHipError, match="different devices"):
+            m1(x.to(D))
