@@ -192,6 +192,27 @@ def cpu_baseline(t, kt=75, n=256):
                       % (n, t, dt)}
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` outside torchrun: run `python -m torch.distributed.run --nproc-per-node N
+    bench.py <same flags>` as a child process (one rank per GPU, RCCL) and return its exit code; rank 0's JSON
+    line goes to our stdout.  On a box with fewer than N GPUs (rehearsal only) the ranks share GPU 0 and the
+    collectives run over gloo through host memory - the line then says so in `rehearsal`."""
+    import socket
+    import subprocess
+    env = dict(os.environ)
+    have = torch.cuda.device_count()          # counts devices without initialising the GPU runtime
+    if have < n:
+        print("bench.py: %d GPUs asked, %d present: REHEARSAL, %d ranks share GPU 0 over gloo" % (n, have, n),
+              file=sys.stderr)
+        env.update(STEP_DIST_BACKEND="gloo", STEP_LOCAL_DEVICE="0", STEP_BENCH_REHEARSAL="1")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -207,6 +228,10 @@ def main():
                          "configs[1]); with f32 a short bf16-operand run is reported beside it")
     ap.add_argument("--no-bf16", action="store_true", help="skip the secondary bf16-operand run")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not under torchrun: start the N ranks ourselves - a fresh child, before anything here touches the GPU
+        sys.exit(self_launch(args.gpus))
 
     from step_amd import parallel
     import torch.distributed as dist
@@ -229,7 +254,7 @@ def main():
     def step():
         out, _ = model(x)
         loss = F.cross_entropy(out, y)
-        opt.zero_grad(set_to_none=True)
+        bucket.zero_grad()                  # one memset of the flat buffer every p.grad is a view of
         loss.backward()
         bucket.all_reduce_mean()
         opt.step()
@@ -325,6 +350,8 @@ def main():
                        "parallelism": "dp%d" % world},
             "inference_sequences_per_s_per_gpu": round(infer, 1),
             "step_tflops_per_gpu": round(9.30e9 * args.batch * args.steps / dt / 1e12, 2),
+            "rehearsal": ("%d ranks share one GPU, collectives over gloo through host memory: not a scaling number"
+                          % world) if os.environ.get("STEP_BENCH_REHEARSAL") else None,
             "bf16_mfma": bf16_run, "roofline": roof, "kernels": kernels, "cpu_baseline": cpu,
         }
         print(json.dumps(line))

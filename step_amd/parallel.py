@@ -63,29 +63,46 @@ def _broadcast(flat, src, group=None):
 
 
 class GradBucket:
-    """All parameters' gradients as ONE flat fp32 buffer -> a single all-reduce per step."""
+    """All parameters' gradients as ONE persistent flat fp32 buffer; every ``p.grad`` is a view into it, so the
+    step's single all-reduce runs on the buffer in place - no ``cat`` before it, no copy back after it.
+
+    Use ``bucket.zero_grad()`` instead of ``optimizer.zero_grad()`` (one memset; ``set_to_none=True`` would drop
+    the views - they are re-attached on the next call if that happened): autograd then accumulates each
+    gradient into its slice in place."""
 
     def __init__(self, params):
         self.params = [p for p in params if p.requires_grad]
         self.numel = sum(p.numel() for p in self.params)
         self.flat = None
+        self._views = []
+
+    def _attach(self):
+        p0 = self.params[0]
+        if self.flat is None or self.flat.device != p0.device:
+            self.flat = torch.zeros(self.numel, dtype=torch.float32, device=p0.device)
+            self._views = []
+            off = 0
+            for p in self.params:
+                if p.dtype != torch.float32:
+                    raise TypeError("GradBucket holds fp32 parameters only")
+                self._views.append(self.flat[off:off + p.numel()].view_as(p))
+                off += p.numel()
+        for p, v in zip(self.params, self._views):
+            if p.grad is not v:
+                if p.grad is not None:
+                    v.copy_(p.grad)
+                p.grad = v
+
+    def zero_grad(self):
+        self._attach()
+        self.flat.zero_()
 
     def all_reduce_mean(self, group=None):
         if not dist.is_initialized() or dist.get_world_size(group) == 1:
             return
-        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.params]
-        flat = torch.cat([g.reshape(-1) for g in grads])
-        _all_reduce_sum(flat, group)
-        flat.div_(dist.get_world_size(group))
-        off = 0
-        for p, g in zip(self.params, grads):
-            n = p.numel()
-            if p.grad is None:
-                p.grad = flat[off:off + n].view_as(p).clone()
-            else:
-                p.grad.copy_(flat[off:off + n].view_as(p))
-            off += n
-        self.flat = flat
+        self._attach()                       # gradients made outside the views (first step) are copied in once
+        _all_reduce_sum(self.flat, group)
+        self.flat.div_(dist.get_world_size(group))
 
 
 def broadcast_parameters(module, src=0, group=None):

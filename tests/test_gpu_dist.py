@@ -1,0 +1,102 @@
+"""GPU: the data-parallel path on the real model.  Two ranks share cuda:0 (RCCL refuses two ranks
+on one device, so the collectives run over gloo through host memory - the same GradBucket / broadcast code
+reduces the device buffer in place under 'nccl'); each runs the real_only classifier on its contiguous half of
+a batch.  The bucket-averaged gradients must equal, BIT FOR BIT, the mean of the two shard gradients a single
+process computes, and broadcast_parameters must make rank 1 start from rank 0's weights."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.util import ckpt
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+_WORKER = r"""
+import os, sys, torch, torch.nn.functional as F, torch.distributed as dist
+sys.path.insert(0, '__ROOT__')
+from step_amd import parallel
+from step_amd.net.classifier import Classifier
+from tests.util import ckpt
+rank, local, world = parallel.init_from_env()
+dev = torch.device("cuda", local)
+torch.cuda.set_device(dev)
+m = Classifier(3, 4, {"strategy": "spatial"})
+m.load_state_dict(ckpt("ckpt_classifier_real_only_epoch395"))
+with torch.no_grad():
+    for p in m.parameters():
+        p.add_(0.01 * rank)                 # ranks start different ...
+m = m.to(dev).train()
+parallel.broadcast_parameters(m)            # ... and are made equal to rank 0
+g = torch.Generator().manual_seed(5)
+X = torch.randn(12, 3, 75, 16, 1, generator=g) * 0.5
+Y = torch.randint(0, 4, (12,), generator=g)
+a, b = parallel.shard_batch(12, rank, world)
+bucket = parallel.GradBucket(m.parameters())
+bucket.zero_grad()
+out, _ = m(X[a:b].to(dev))
+F.cross_entropy(out, Y[a:b].to(dev)).backward()
+assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(bucket.params, bucket._views))   # still views
+bucket.all_reduce_mean()
+torch.cuda.synchronize()
+torch.save({"flat": bucket.flat.cpu(), "w0": next(m.parameters()).detach().cpu(),
+            "rm": m.st_gcn_networks[0].tcn[0].running_mean.cpu()}, '__OUT__/rank%d.pt' % rank)
+dist.barrier(); dist.destroy_process_group()
+sys.stdout.write("rank%d-ok\n" % rank); sys.stdout.flush()
+"""
+
+
+def test_two_rank_gradients_equal_mean_of_shard_gradients(tmp_path):
+    from step_amd import parallel
+    from step_amd.net.classifier import Classifier
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER.replace("__ROOT__", ROOT).replace("__OUT__", str(tmp_path)))
+    env = dict(os.environ, STEP_DIST_BACKEND="gloo", STEP_LOCAL_DEVICE="0", OMP_NUM_THREADS="2",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29531", str(script)],
+                         env=env, capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    r0 = torch.load(tmp_path / "rank0.pt", weights_only=True)
+    r1 = torch.load(tmp_path / "rank1.pt", weights_only=True)
+    assert torch.equal(r0["flat"], r1["flat"])                    # every rank holds the same averaged gradients
+    assert torch.equal(r0["w0"], r1["w0"])                        # broadcast made the ranks equal
+
+    # single process: gradients of each contiguous shard (per-shard BN statistics = DDP semantics), then the mean
+    D = "cuda:0"
+    g = torch.Generator().manual_seed(5)
+    X = torch.randn(12, 3, 75, 16, 1, generator=g) * 0.5
+    Y = torch.randint(0, 4, (12,), generator=g)
+    flats, rms = [], []
+    for rank in range(2):
+        m = Classifier(3, 4, {"strategy": "spatial"})
+        m.load_state_dict(ckpt("ckpt_classifier_real_only_epoch395"))
+        m = m.to(D).train()
+        a, b = parallel.shard_batch(12, rank, 2)
+        o, _ = m(X[a:b].to(D))
+        F.cross_entropy(o, Y[a:b].to(D)).backward()
+        flats.append(torch.cat([p.grad.reshape(-1) for p in m.parameters()]).cpu())
+        rms.append(m.st_gcn_networks[0].tcn[0].running_mean.cpu())
+    want = (flats[0] + flats[1]) / 2
+    assert torch.equal(r0["flat"], want), float((r0["flat"] - want).abs().max())
+    assert torch.equal(r0["rm"], rms[0]) and torch.equal(r1["rm"], rms[1])    # BN statistics stay per rank
+    assert torch.equal(r0["w0"], next(m.parameters()).detach().cpu())
+
+
+def test_bench_self_launch_two_ranks():
+    """`python bench.py --gpus 2` outside torchrun starts its own ranks (a child torchrun; here both ranks share
+    the one GPU in rehearsal mode) and prints rank 0's JSON line with n_gpus = 2"""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--batch", "64", "--no-cpu", "--no-kernels", "--no-infer", "--no-bf16"],
+                         env=env, capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 128 and line["value"] > 0
+    if torch.cuda.device_count() < 2:
+        assert line["rehearsal"]
