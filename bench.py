@@ -174,9 +174,9 @@ def time_hbm_kernels(n, t, device, reps=3):
     return out
 
 
-def cpu_baseline(t, kt=75, n=256):
+def cpu_baseline(t, kt=75, n=192):
     """The oracle (port of the reference's PyTorch CPU path) on a bounded sample: fwd+bwd of n
-    sequences at the bench's T, on the box's host cores."""
+    sequences at the bench's T, on the box's host cores; median of 3 passes."""
     from oracle import stgcn
     threads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
     torch.set_num_threads(threads)
@@ -184,12 +184,56 @@ def cpu_baseline(t, kt=75, n=256):
     P = {k: v.clone() for k, v in m.state_dict().items()}
     x, y = synth(n, t, 99, "cpu")
     stgcn.classifier_loss_and_grads(P, x[:2], y[:2], "real_only")          # warm-up
-    t0 = time.perf_counter()
-    stgcn.classifier_loss_and_grads(P, x, y, "real_only")
-    dt = time.perf_counter() - t0
+    dts = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        stgcn.classifier_loss_and_grads(P, x, y, "real_only")
+        dts.append(time.perf_counter() - t0)
+    dt = sorted(dts)[1]
     return {"value": round(n / dt, 3), "unit": "sequences/s", "cores": threads, "kind": "port",
-            "sample": "oracle fwd+bwd (CrossEntropy, no optimizer), N=%d x 3 x %d x 16 fp32, %.1f s"
-                      % (n, t, dt)}
+            "sample": "oracle fwd+bwd (CrossEntropy, no optimizer), N=%d x 3 x %d x 16 fp32, median of 3 passes "
+                      "(%.1f s each); torch CPU kernels with oneDNN DISABLED (its conv backward is unusable for "
+                      "these (Kt,1) kernels on this image, oracle/stgcn.py:31-37) - the reference's default CPU "
+                      "path would run its convolutions through oneDNN" % (n, t, dt)}
+
+
+def model_flops_per_sequence(t, kt=75, k=3):
+    """algorithmic forward FLOPs of one sequence through the real_only stack (SURVEY 8d formulas):
+    gcn 2*Ci*K*Co*T*V, dense aggregation 2*K*Co*T*V^2, tcn 2*Co^2*Kt*To*V, residual conv 2*Ci*Co*To*V"""
+    fl, ci, tt = 0.0, 3, t
+    for co, s in ((32, 1), (64, 2), (64, 1)):
+        to = (tt - 1) // s + 1
+        fl += 2.0 * ci * k * co * tt * 16 + 2.0 * k * co * tt * 16 * 16 + 2.0 * co * co * kt * to * 16
+        if ci != co or s != 1:
+            fl += 2.0 * ci * co * to * 16
+        ci, tt = co, to
+    return fl
+
+
+def _sha256(paths):
+    import hashlib
+    h = hashlib.sha256()
+    for p in paths:
+        with open(os.path.join(ROOT, p), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def pmc_traffic(kernel, batch, frames):
+    """HBM bytes per launch of the dominant kernel from the PMC passes of tools/gpu_round.sh
+    (profiles/pmc_traffic.json).  Used only when that file was measured on THIS kernel source (sha256 of the
+    .hip files recorded in it) at this shape; otherwise null - a stale number is worse than none."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
+            pmc = json.load(fh)
+        ent = pmc.get(kernel)
+        if ent and pmc.get("batch") == batch and pmc.get("frames") == frames \
+                and pmc.get("source_sha256") == _sha256(pmc.get("sources", [])):
+            return ent["hbm_bytes"], {"file": "profiles/pmc_traffic.json", "git_sha": pmc.get("git_sha"),
+                                      "source_sha256": pmc.get("source_sha256")[:16]}
+    except (OSError, ValueError, KeyError, TypeError):
+        pass
+    return None, None
 
 
 def self_launch(n):
@@ -319,16 +363,10 @@ def main():
         if args.mfma == "f32":          # MFMA utilisation of the wide layers (kernel-level bench points, N = batch / 2)
             torch.cuda.empty_cache()
             kernels = kernels + time_kernels(max(1, args.batch // 2), args.frames, device, blocks=WIDE_BLOCKS, tag="wide")
-        traffic = None
-        try:    # HBM bytes per launch from the committed PMC passes (same shape, N=4096 only)
-            with open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")) as fh:
-                pmc = json.load(fh)
-            if args.batch == 4096 and args.frames == 240 and args.mfma == "f32" and dom["kernel"] in pmc:
-                traffic = pmc[dom["kernel"]]["hbm_bytes"]
-        except (OSError, ValueError):
-            pass
+        traffic, traffic_src = (pmc_traffic(dom["kernel"], args.batch, args.frames) if args.mfma == "f32"
+                                else (None, None))
         roof = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"],
-                "peak": PEAK_BF16_MFMA_TFLOPS if args.mfma == "bf16" else PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": dom["frac"], "traffic": traffic,
+                "peak": PEAK_BF16_MFMA_TFLOPS if args.mfma == "bf16" else PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": dom["frac"], "traffic": traffic, "traffic_source": traffic_src,
                 "flops_per_launch": tcn_flops(args.batch, dom["C"], (args.frames - 1) // 2 + 1
                                               if dom["kernel"].endswith(("b1", "b2")) else args.frames)}
     cpu = None
@@ -349,7 +387,7 @@ def main():
                        "global_batch": args.batch * world, "frames": args.frames,
                        "parallelism": "dp%d" % world},
             "inference_sequences_per_s_per_gpu": round(infer, 1),
-            "step_tflops_per_gpu": round(9.30e9 * args.batch * args.steps / dt / 1e12, 2),
+            "step_tflops_per_gpu": round(3.0 * model_flops_per_sequence(args.frames) * args.batch * args.steps / dt / 1e12, 2),
             "rehearsal": ("%d ranks share one GPU, collectives over gloo through host memory: not a scaling number"
                           % world) if os.environ.get("STEP_BENCH_REHEARSAL") else None,
             "bf16_mfma": bf16_run, "roofline": roof, "kernels": kernels, "cpu_baseline": cpu,
