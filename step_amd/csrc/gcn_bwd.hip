@@ -609,6 +609,437 @@ __global__ __launch_bounds__(256, CIP <= 8 ? 2 : 1) void gcn_bwd_weight_kernel(G
     }
 }
 
+
+// ==========================================================================================================
+// Second form of the backward for the wide blocks (Ci, Co in {32, 64}; no data_bn on the load).
+//
+// Every product runs on v_mfma_f32_16x16x4_f32 with one (n, t) FRAME as the column tile (16 joints), and every
+// operand reaches the matrix cores in the layout the producing instruction (a global load or an MFMA) left it in:
+// no LDS tiles, no barriers inside the loops, waves are autonomous.  Two waves per SIMD (the kernels stay under
+// 256 VGPRs), so one wave's VALU / load / store phase runs beside its partner's MFMAs.  Lane = 16 q + l.
+//
+// data kernel, wave = one frame at a time:
+//   dz_k[ci,w]   = SUM_c W_k[c,ci] dy[c,t,w]        A[i=ci][q] = W_k[4s+q][ci] (LDS, read-only),  B[q][j=w] = dy[4s+q][t][w]
+//                                                   (the lane's own 4-byte load); D register r of lane (q,w) = dz_k[4q+r][w]
+//   dA_k[v,w]   += SUM_ci x[ci,t,v] dz_k[ci,w]      A[i=v][q] = x[4q+r][t][v] (own load),  B = D register r of dz as it lies
+//   dx[ci,t,v]   = SUM_k SUM_w A_k[v,w] dz_k[ci,w]  along the 16 lanes of a row: DPP row rotations, live rotations only
+//                  (+ SUM_c Wr[c,ci] dres[c,t',w]: one more MFMA chain with the dz layout)
+// weight kernel, wave = (16 input channels, one frame at a time):
+//   z_k[ci,w]    = SUM_v x[ci,t,v] A_k[v,w]         A[i=w][q] = A_k[4q+e][w] (registers),  B[q][j=ci] = component e of the
+//                                                   lane's float4 x[ci][t][4q..4q+3];  D register r of lane (q,ci) = z_k[ci][4q+r]
+//   dW_k[c,ci]  += SUM_w dy[c,t,w] z_k[ci,w]        A[i=c][q] = component r of the lane's float4 dy[c][t][4q..4q+3],  B = D register
+//                                                   r of z_k as it lies;  dWr the same with x itself as B
+// Per-block partials go through the same ordered finalize as the first form (bit-reproducible).
+// Measured (N = 4096): block 1 (32 -> 64, stride-2 residual) 8.4 -> 6.0 ms, block 2 (64 -> 64) 6.5 -> 4.5 ms for the two
+// kernels.  What bounds them now: in these kernels a v_mfma_f32_16x16x4_f32 takes ~38-41 cycles instead of its 32-cycle
+// issue rate (MFMA-only ablation of the data kernel: 78 % of the pipe; a register-only probe of the same instruction
+// reaches 32.0, tools/mfma_data_probe2.hip), every VALU instruction of a wave ADDS to its fp32 MFMA time
+// (tools/mfma_shape_probe.hip: same wave additive, a partner wave's VALU does overlap), and the clock sits at
+// 1.9-2.05 GHz while both kernels stream x and dy from HBM.  Staggering / prioritising the SIMD partners changed nothing.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int CT>
+__device__ __forceinline__ void lds_frag(const float* p, float (&out)[CT]) {
+    if constexpr (CT == 4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(p);
+        out[0] = v[0]; out[1] = v[1]; out[2] = v[2]; out[3] = v[3];
+    } else {
+        const f32x2 v = *reinterpret_cast<const f32x2*>(p);
+        out[0] = v[0]; out[1] = v[1];
+    }
+}
+
+// raw buffer access: descriptor (uniform base) + 32-bit lane offset + uniform SGPR offset - no 64-bit VALU address
+// arithmetic per access (it would all add to the MFMA time: fp32 MFMAs and the same wave's VALU do not overlap)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7ffffffc, 0x00020000);
+}
+__device__ __forceinline__ float bload(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+}
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 bload4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ void bstore(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)voff, (int)soff, 0);
+}
+
+// acc += c * (src rotated right by R lanes inside its row of 16) as ONE instruction.  hipcc leaves
+// __builtin_amdgcn_mov_dpp + fmaf as v_mov_b32_dpp + (SLP-packed) v_pk_fma_f32 - twice the VALU work, and every VALU
+// cycle of this wave adds to its fp32 MFMA time.  `first` pads the SALU-writes-EXEC -> DPP hazard (5 wait states)
+// that the compiler does not see through an asm statement; the DPP source is an MFMA result that is dozens of MFMAs
+// old by the time these run (the callers fence with sched_barrier).
+template <int R>
+__device__ __forceinline__ void fma_ror(float& acc, float c, float src, bool first) {
+    if constexpr (R == 0) {
+        acc = fmaf(c, src, acc);
+    } else if (first) {
+        asm volatile("s_nop 4\n\tv_fmac_f32_dpp %0, %1, %2 row_ror:%3 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+                     : "+v"(acc) : "v"(src), "v"(c), "i"(R));
+    } else {
+        asm volatile("v_fmac_f32_dpp %0, %1, %2 row_ror:%3 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+                     : "+v"(acc) : "v"(src), "v"(c), "i"(R));
+    }
+}
+
+template <int CI, int CO, int RES>
+__global__ __launch_bounds__(512, 2) void gcn_bwd_data16_kernel(GbParams p) {
+    constexpr int CT = CI / 16;                       // 16-channel tiles of ci
+    constexpr int S = CO / 4;                         // k-steps over c (4 output channels each)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Wl = smem;                                 // [3][S][64 lanes][CT]
+    float* Wrl = Wl + 3 * S * 64 * CT;                // [S][64][CT]   (RES)
+    float* cfs = Wrl + (RES ? S * 64 * CT : 0);       // [3][16 joints][16 rotations]
+    float* red = smem;                                // [8][768], after the loop
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // provably uniform: rows, descriptors, offsets in SGPRs
+    const int q = lane >> 4, l16 = lane & 15;
+
+    for (int e = tid; e < 3 * S * 64 * CT; e += 512) {
+        const int tile = e % CT, ln = (e / CT) & 63, s = (e / (CT * 64)) % S, k = e / (CT * 64 * S);
+        const int c = 4 * s + (ln >> 4), ci = 16 * tile + (ln & 15);
+        float v = 0.f;
+        if (k < p.K)
+            v = p.w_transposed ? p.w[(size_t)ci * (p.K * CO) + k * CO + c] : p.w[((size_t)k * CO + c) * CI + ci];
+        Wl[e] = v;
+    }
+    if constexpr (RES != 0) {
+        for (int e = tid; e < S * 64 * CT; e += 512) {
+            const int tile = e % CT, ln = (e / CT) & 63, s = e / (CT * 64);
+            const int c = 4 * s + (ln >> 4), ci = 16 * tile + (ln & 15);
+            Wrl[e] = p.res_transposed ? p.res_w[(size_t)ci * CO + c] : p.res_w[(size_t)c * CI + ci];
+        }
+    }
+    // rotation coefficients: cf[k][R] = A[k][v = this lane's joint][w = joint of the lane row_ror:R brings here]
+    unsigned rmask[3] = {0u, 0u, 0u};
+    static_for<0, 16>([&](auto rt) {
+        constexpr int R = decltype(rt)::value;
+        const int src = __float_as_int(row_ror<R>(__int_as_float(l16)));
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float a = (k < p.K) ? p.A[(k * 16 + l16) * 16 + src] : 0.f;
+            if (tid < 16) cfs[(k * 16 + l16) * 16 + R] = a;
+            if (__ballot(a != 0.f) != 0ull) rmask[k] |= 1u << R;
+        }
+    });
+#pragma unroll
+    for (int k = 0; k < 3; ++k) rmask[k] = __builtin_amdgcn_readfirstlane(rmask[k]);
+    __syncthreads();
+
+    f32x4 dAk[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) dAk[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // this wave's contiguous run of frames
+    const long long R = (long long)p.N * p.T;
+    const long long nw = (long long)gridDim.x * 8, gw = (long long)blockIdx.x * 8 + wave;
+    const long long r0 = R * gw / nw, r1 = R * (gw + 1) / nw;
+    const int nrows = (int)(r1 - r0);
+
+    // Addresses: per-sample buffer descriptors (SGPRs), ONE 32-bit lane offset per tensor, and the channel-step /
+    // frame part as a uniform SGPR offset computed on the scalar unit.  Bytes.
+    const unsigned TS = (unsigned)p.T * 64u, TOS = (unsigned)p.To * 64u;      // bytes per channel row
+    const unsigned lane_dy = (unsigned)q * TS + l16 * 4u, lane_x = 4u * q * TS + l16 * 4u;
+    const unsigned lane_dr = (unsigned)q * TOS + l16 * 4u;
+    int n = (int)(r0 / p.T), t = (int)(r0 - (long long)n * p.T);
+
+    float dyA[S], dyB[S];
+    auto load_dy = [&](int nn, int tt, float (&dyv)[S]) {
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(p.dy + (size_t)nn * CO * p.T * 16);
+        const unsigned so = (unsigned)tt * 64u;
+#pragma unroll
+        for (int s = 0; s < S; ++s) dyv[s] = bload(rs, lane_dy, so + (unsigned)s * 4u * TS);
+    };
+    auto do_row = [&](int nn, int tt, bool have_next, float (&dyc)[S], float (&dyn)[S]) {
+        const bool res_row = RES == 1 || (RES == 2 && (tt & 1) == 0);
+        float xc[CT * 4], drc[RES ? S : 1];
+        {
+            const __amdgpu_buffer_rsrc_t rs = make_rsrc(p.x + (size_t)nn * CI * p.T * 16);
+            const unsigned so = (unsigned)tt * 64u;
+#pragma unroll
+            for (int i = 0; i < CT * 4; ++i) xc[i] = bload(rs, lane_x, so + (unsigned)((i >> 2) * 16 + (i & 3)) * TS);
+        }
+        if constexpr (RES != 0) {
+            if (res_row) {
+                const __amdgpu_buffer_rsrc_t rs = make_rsrc(p.dres + (size_t)nn * CO * p.To * 16);
+                const unsigned so = (unsigned)(RES == 1 ? tt : tt >> 1) * 64u;
+#pragma unroll
+                for (int s = 0; s < S; ++s) drc[s] = bload(rs, lane_dr, so + (unsigned)s * 4u * TOS);
+            }
+        }
+        if (have_next) {
+            int n2 = nn, t2 = tt + 1;
+            if (t2 == p.T) { t2 = 0; ++n2; }
+            load_dy(n2, t2, dyn);
+        }
+
+        // dz_k = W_k^T dy; the W fragments of step s + 1 are read while step s multiplies
+        f32x4 dz[3][CT];
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int j = 0; j < CT; ++j) dz[k][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float wf[3][CT], wn[3][CT];
+        const float* wl = Wl + (size_t)lane * CT;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) lds_frag<CT>(wl + (size_t)(k * S) * 64 * CT, wf[k]);
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            if (s + 1 < S) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) lds_frag<CT>(wl + (size_t)(k * S + s + 1) * 64 * CT, wn[k]);
+            }
+            __builtin_amdgcn_sched_barrier(0);        // the reads of step s + 1 stay AHEAD of step s's MFMAs
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int j = 0; j < CT; ++j)
+                    dz[k][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[k][j], dyc[s], dz[k][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int j = 0; j < CT; ++j) wf[k][j] = wn[k][j];
+        }
+        // residual branch: SUM_c Wr[c,ci] dres[c,t',w] has dz's layout and adds straight into dx
+        f32x4 dxa[CT];
+#pragma unroll
+        for (int j = 0; j < CT; ++j) dxa[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (RES != 0) {
+            if (res_row) {
+                const float* wr = Wrl + (size_t)lane * CT;
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    float wv[CT];
+                    lds_frag<CT>(wr + (size_t)s * 64 * CT, wv);
+#pragma unroll
+                    for (int j = 0; j < CT; ++j)
+                        dxa[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[j], drc[s], dxa[j], 0, 0, 0);
+                    if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        // the lane's rotation coefficients (16 per partition, 12 wide LDS reads) arrive under the dA chain
+        f32x4 cf[3][4];
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) cf[k][g] = *reinterpret_cast<const f32x4*>(cfs + (k * 16 + l16) * 16 + 4 * g);
+        // dA_k += x^T dz_k
+#pragma unroll
+        for (int j = 0; j < CT; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+                    dAk[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(xc[j * 4 + r], dz[k][j][r], dAk[k], 0, 0, 0);
+        // dx = SUM_k A_k dz_k along the lanes of the frame
+        if (p.dx) {
+            float dxr[CT * 4];
+#pragma unroll
+            for (int j = 0; j < CT; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dxr[j * 4 + r] = dxa[j][r];
+            __builtin_amdgcn_sched_barrier(0);
+            static_for<0, 3>([&](auto kt) {
+                constexpr int kq = decltype(kt)::value;
+                static_for<0, 16>([&](auto rt) {
+                    constexpr int RR = decltype(rt)::value;
+                    if ((rmask[kq] >> RR) & 1u) {
+                        const float c = cf[kq][RR >> 2][RR & 3];
+#pragma unroll
+                        for (int j = 0; j < CT; ++j)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                fma_ror<RR>(dxr[j * 4 + r], c, dz[kq][j][r], j == 0 && r == 0);
+                    }
+                });
+            });
+            const __amdgpu_buffer_rsrc_t rs = make_rsrc(p.dx + (size_t)nn * CI * p.T * 16);
+            const unsigned so = (unsigned)tt * 64u;
+#pragma unroll
+            for (int i = 0; i < CT * 4; ++i) bstore(rs, lane_x, so + (unsigned)((i >> 2) * 16 + (i & 3)) * TS, dxr[i]);
+        }
+    };
+
+    if (nrows > 0) load_dy(n, t, dyA);
+    for (int i = 0; i < nrows; i += 2) {
+        do_row(n, t, i + 1 < nrows, dyA, dyB);
+        if (++t == p.T) { t = 0; ++n; }
+        if (i + 1 < nrows) {
+            do_row(n, t, i + 2 < nrows, dyB, dyA);
+            if (++t == p.T) { t = 0; ++n; }
+        }
+    }
+
+    // block partial of dA (dense 16 x 16 per k): D register i of lane l = dA[k][4*(l>>4)+i][l&15]
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) red[wave * 768 + (k * 16 + 4 * q + i) * 16 + l16] = dAk[k][i];
+    __syncthreads();
+    for (int e = tid; e < 768; e += 512) {
+        float sum = 0.f;
+#pragma unroll
+        for (int w8 = 0; w8 < 8; ++w8) sum += red[w8 * 768 + e];
+        p.part1[(size_t)blockIdx.x * 768 + e] = sum;
+    }
+}
+
+// weight kernel: 512-thread blocks = 8 waves = (CI / 16 input-channel tiles) x (8 / CIT frame streams)
+template <int CI, int CO>
+__global__ __launch_bounds__(512, 2) void gcn_bwd_weight16_kernel(GbParams p) {
+    constexpr int CIT = CI / 16, COT = CO / 16;
+    constexpr int SPB = 8 / CIT;                      // frame streams per block (waves sharing a ci tile)
+    constexpr int PART = 3 * CO * CI + CO * 16 + CO * CI + CO;
+    constexpr int PW = (4 * COT) * 4 + 2 * COT * 4;   // accumulator floats per lane
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // [SPB - 1][CIT][64][PW]: the other streams' sums
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // provably uniform: rows, descriptors, offsets in SGPRs
+    const int q = lane >> 4, l16 = lane & 15;
+    const int cit = wave % CIT, sib = wave / CIT;
+
+    // A operand of the aggregation: A[i = w][k' = q] of step e = A_k[v = 4q + e][w]
+    float akt[3][4];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) akt[k][e] = (k < p.K) ? p.A[(k * 16 + 4 * q + e) * 16 + l16] : 0.f;
+
+    f32x4 acc[3][COT], accr[COT];
+    f32x4 Sacc[COT], Bacc[COT];
+#pragma unroll
+    for (int ct = 0; ct < COT; ++ct) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) acc[k][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+        accr[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+        Sacc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+        Bacc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    const long long R = (long long)p.N * p.T;
+    const long long ns = (long long)gridDim.x * SPB, gs = (long long)blockIdx.x * SPB + sib;
+    const long long r0 = R * gs / ns, r1 = R * (gs + 1) / ns;
+    const int nrows = (int)(r1 - r0);
+    const bool have_res = p.dres != nullptr;
+    const unsigned TS = (unsigned)p.T * 64u, TOS = (unsigned)p.To * 64u;
+    const unsigned lane_x = (unsigned)(16 * cit + l16) * TS + q * 16u;
+    const unsigned lane_dy = (unsigned)l16 * TS + q * 16u, lane_dr = (unsigned)l16 * TOS + q * 16u;
+    int n = (int)(r0 / p.T), t = (int)(r0 - (long long)n * p.T);
+
+    struct Row { f32x4 x, dy[COT], dr[COT]; };
+    auto load_row = [&](int nn, int tt, Row& rw) {
+        const unsigned so = (unsigned)tt * 64u;
+        rw.x = bload4(make_rsrc(p.x + (size_t)nn * CI * p.T * 16), lane_x, so);
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(p.dy + (size_t)nn * CO * p.T * 16);
+#pragma unroll
+        for (int ct = 0; ct < COT; ++ct) rw.dy[ct] = bload4(rs, lane_dy, so + (unsigned)ct * 16u * TS);
+        if (have_res && (p.stride == 1 || (tt & 1) == 0)) {
+            const __amdgpu_buffer_rsrc_t rr = make_rsrc(p.dres + (size_t)nn * CO * p.To * 16);
+            const unsigned sr = (unsigned)(p.stride == 1 ? tt : tt >> 1) * 64u;
+#pragma unroll
+            for (int ct = 0; ct < COT; ++ct) rw.dr[ct] = bload4(rr, lane_dr, sr + (unsigned)ct * 16u * TOS);
+        }
+    };
+    auto do_row = [&](int nn, int tt, bool have_next, Row& cur, Row& nxt) {
+        if (have_next) {
+            int n2 = nn, t2 = tt + 1;
+            if (t2 == p.T) { t2 = 0; ++n2; }
+            load_row(n2, t2, nxt);
+        }
+        // z_k = x A_k
+        f32x4 z[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            z[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) z[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(akt[k][e], cur.x[e], z[k], 0, 0, 0);
+        }
+#pragma unroll
+        for (int ct = 0; ct < COT; ++ct) {
+            if (cit == 0) Sacc[ct] += cur.dy[ct];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+                    acc[k][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.dy[ct][r], z[k][r], acc[k][ct], 0, 0, 0);
+        }
+        if (have_res && (p.stride == 1 || (tt & 1) == 0)) {
+#pragma unroll
+            for (int ct = 0; ct < COT; ++ct) {
+                if (cit == 0) Bacc[ct] += cur.dr[ct];
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    accr[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.dr[ct][r], cur.x[r], accr[ct], 0, 0, 0);
+            }
+        }
+    };
+
+    Row ra, rb;
+    if (nrows > 0) load_row(n, t, ra);
+    for (int i = 0; i < nrows; i += 2) {
+        do_row(n, t, i + 1 < nrows, ra, rb);
+        if (++t == p.T) { t = 0; ++n; }
+        if (i + 1 < nrows) {
+            do_row(n, t, i + 2 < nrows, rb, ra);
+            if (++t == p.T) { t = 0; ++n; }
+        }
+    }
+
+    // the streams of a block that share a ci tile are summed through LDS in stream order
+    if (sib > 0) {
+        float* st = smem + (((size_t)(sib - 1) * CIT + cit) * 64 + lane) * PW;
+#pragma unroll
+        for (int ct = 0; ct < COT; ++ct) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) *reinterpret_cast<f32x4*>(st + (k * COT + ct) * 4) = acc[k][ct];
+            *reinterpret_cast<f32x4*>(st + (3 * COT + ct) * 4) = accr[ct];
+            *reinterpret_cast<f32x4*>(st + 16 * COT + ct * 8) = Sacc[ct];
+            *reinterpret_cast<f32x4*>(st + 16 * COT + ct * 8 + 4) = Bacc[ct];
+        }
+    }
+    __syncthreads();
+    if (sib == 0) {
+#pragma unroll 1
+        for (int o = 1; o < SPB; ++o) {
+            const float* st = smem + (((size_t)(o - 1) * CIT + cit) * 64 + lane) * PW;
+#pragma unroll
+            for (int ct = 0; ct < COT; ++ct) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) acc[k][ct] += *reinterpret_cast<const f32x4*>(st + (k * COT + ct) * 4);
+                accr[ct] += *reinterpret_cast<const f32x4*>(st + (3 * COT + ct) * 4);
+                Sacc[ct] += *reinterpret_cast<const f32x4*>(st + 16 * COT + ct * 8);
+                Bacc[ct] += *reinterpret_cast<const f32x4*>(st + 16 * COT + ct * 8 + 4);
+            }
+        }
+        float* part = p.part2 + (size_t)blockIdx.x * PART;
+        const int ci = 16 * cit + l16;
+#pragma unroll
+        for (int ct = 0; ct < COT; ++ct) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = 16 * ct + 4 * q + r;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) part[(k * CO + c) * CI + ci] = acc[k][ct][r];
+                part[3 * CO * CI + CO * 16 + c * CI + ci] = accr[ct][r];
+            }
+            if (cit == 0) {
+                const int c = 16 * ct + l16;                      // the lane's dy row
+                float* ps = part + 3 * CO * CI + c * 16 + 4 * q;
+                ps[0] = Sacc[ct][0]; ps[1] = Sacc[ct][1]; ps[2] = Sacc[ct][2]; ps[3] = Sacc[ct][3];
+                float b = (Bacc[ct][0] + Bacc[ct][1]) + (Bacc[ct][2] + Bacc[ct][3]);
+                b += __shfl_xor(b, 16, 64);
+                b += __shfl_xor(b, 32, 64);
+                if (q == 0) part[3 * CO * CI + CO * 16 + CO * CI + c] = b;
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------- finalize
 struct FinParams {
     const float* part1; const float* part2; const float* A; const float* b;
@@ -733,6 +1164,54 @@ bool gb_geom(int N, int Ci, int Co, int T, int nnz, GbGeom* g) {
     return g->lds1 <= 160 * 1024 && g->lds2 <= 160 * 1024;
 }
 
+// second form: blocks for the data / weight kernels (two 256-thread blocks per CU, fewer for tiny inputs)
+bool gb16_shape(int Ci, int Co, const float* in_scale) {
+    return !in_scale && (Ci == 32 || Ci == 64) && (Co == 32 || Co == 64) && !getenv("STEP_GCN_BWD_V1");
+}
+
+int gb16_blocks(int N, int T) {
+    const long long rows = (long long)N * T;
+    const long long b = (rows + 15) / 16;             // 8 waves per block, at least two frames per wave
+    return (int)(b < 1 ? 1 : (b > 256 ? 256 : b));
+}
+
+template <int CI, int CO>
+int launch_gb16(const GbParams& p, int nblk, hipStream_t st) {
+    const int res = p.dres ? p.stride : 0;
+    size_t lds1 = ((size_t)(3 + (res ? 1 : 0)) * (CO / 4) * 64 * (CI / 16) + 768) * 4;
+    if (lds1 < 8 * 768 * 4) lds1 = 8 * 768 * 4;
+    constexpr int CIT = CI / 16, COT = CO / 16;
+    const size_t lds2 = (size_t)(8 / CIT - 1) * CIT * 64 * (24 * COT) * 4;
+    auto k2 = gcn_bwd_weight16_kernel<CI, CO>;
+    hipError_t e = hipSuccess;
+    auto attr = [&](const void* k, size_t lds) {
+        if (e == hipSuccess && lds > 64 * 1024)
+            e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    };
+    attr(reinterpret_cast<const void*>(k2), lds2);
+    if (res == 0) {
+        attr(reinterpret_cast<const void*>(gcn_bwd_data16_kernel<CI, CO, 0>), lds1);
+        if (e == hipSuccess) hipLaunchKernelGGL((gcn_bwd_data16_kernel<CI, CO, 0>), dim3(nblk), dim3(512), lds1, st, p);
+    } else if (res == 1) {
+        attr(reinterpret_cast<const void*>(gcn_bwd_data16_kernel<CI, CO, 1>), lds1);
+        if (e == hipSuccess) hipLaunchKernelGGL((gcn_bwd_data16_kernel<CI, CO, 1>), dim3(nblk), dim3(512), lds1, st, p);
+    } else {
+        attr(reinterpret_cast<const void*>(gcn_bwd_data16_kernel<CI, CO, 2>), lds1);
+        if (e == hipSuccess) hipLaunchKernelGGL((gcn_bwd_data16_kernel<CI, CO, 2>), dim3(nblk), dim3(512), lds1, st, p);
+    }
+    if (e != hipSuccess) {
+        step::set_error("step_gcn_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        return STEP_ERR_LAUNCH;
+    }
+    hipLaunchKernelGGL(k2, dim3(nblk), dim3(512), lds2, st, p);
+    return step::check_launch("step_gcn_bwd");
+}
+
+int dispatch_gb16(const GbParams& p, int nblk, hipStream_t st) {
+    if (p.Ci == 32) return p.Co == 32 ? launch_gb16<32, 32>(p, nblk, st) : launch_gb16<32, 64>(p, nblk, st);
+    return p.Co == 32 ? launch_gb16<64, 32>(p, nblk, st) : launch_gb16<64, 64>(p, nblk, st);
+}
+
 template <int CIP, int COPAD, bool RES>
 int launch_gb(const GbParams& p, const GbGeom& g, hipStream_t st) {
     auto k1 = gcn_bwd_data_kernel<CIP, COPAD, RES>;
@@ -772,6 +1251,10 @@ int dispatch_gb(const GbParams& p, const GbGeom& g, hipStream_t st) {
 extern "C" size_t step_gcn_bwd_ws_bytes(int N, int Ci, int Co, int K, int T) {
     (void)K;
     size_t best = 0;
+    if ((Ci == 32 || Ci == 64) && (Co == 32 || Co == 64) && N >= 1 && T >= 1) {      // second form
+        const size_t nb = (size_t)gb16_blocks(N, T);
+        best = (nb + 1) * ((size_t)768 + 3 * (size_t)Co * Ci + (size_t)Co * 16 + (size_t)Co * Ci + Co) * 4;
+    }
     for (int nnz = 4; nnz <= 16; nnz += 12) {             // both kernel variants
         GbGeom g;
         if (!gb_geom(N, Ci, Co, T, nnz, &g)) continue;
@@ -795,13 +1278,20 @@ extern "C" int step_gcn_bwd(const float* dy, const float* dres, const float* x, 
     GbGeom g;
     STEP_REQUIRE(gb_geom(N, Ci, Co, T, a_nnz_max, &g), "step_gcn_bwd: unsupported N=%d Ci=%d Co=%d T=%d", N,
                  Ci, Co, T);
+    const bool v2 = gb16_shape(Ci, Co, in_scale);
+    if (v2) {
+        g.nblk1 = g.nblk2 = gb16_blocks(N, T);
+        g.copad = Co; g.cir = Ci;
+        g.part1 = 768;
+        g.part2 = 3 * (size_t)Co * Ci + (size_t)Co * 16 + (size_t)Co * Ci + Co;
+    }
     const size_t need = ((size_t)(g.nblk1 + 1) * g.part1 + (size_t)(g.nblk2 + 1) * g.part2) * 4;
     if (ws_bytes < need) {
         step::set_error("step_gcn_bwd: workspace %zu < %zu bytes", ws_bytes, need);
         return STEP_ERR_WORKSPACE;
     }
     const int nblk1_ws = g.nblk1;                    // rows the workspace was sized for
-    if (dres) {
+    if (dres && !v2) {
         // the residual product keeps Wr and the dres tile in LDS too: fewer blocks per CU, never more
         const int cirp = g.cip <= 32 ? 32 : 64;
         g.lds1 += ((size_t)g.copad * cirp + (size_t)g.copad * (stride == 1 ? P : P / 2)) * 4;
@@ -822,7 +1312,7 @@ extern "C" int step_gcn_bwd(const float* dy, const float* dres, const float* x, 
     p.tiles_per_seq = (T + TT - 1) / TT;
     p.ntiles = N * p.tiles_per_seq;
     hipStream_t st = (hipStream_t)stream;
-    int rc = dispatch_gb(p, g, st);
+    int rc = v2 ? dispatch_gb16(p, g.nblk1, st) : dispatch_gb(p, g, st);
     if (rc) return rc;
     float* tot1 = p.part2 + (size_t)g.nblk2 * g.part2;   // (workspace rows: nblk1_ws + nblk2 + 2)
     float* tot2 = tot1 + g.part1;
