@@ -33,6 +33,23 @@ int wgrad_sw(const float* dout, const float* in, const float* in_scale, const fl
 
 }  // namespace step
 
+// raw buffer access: descriptor (uniform base) + 32-bit lane offset + uniform SGPR offset - no 64-bit VALU address
+// arithmetic per access (it would all add to the MFMA time: fp32 MFMAs and the same wave's VALU do not overlap)
+static __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7ffffffc, 0x00020000);
+}
+static __device__ __forceinline__ float bload(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+}
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+static __device__ __forceinline__ f32x4 bload4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+}
+static __device__ __forceinline__ void bstore(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)voff, (int)soff, 0);
+}
+
+
 #define STEP_REQUIRE(cond, ...)                         \
     do {                                                \
         if (!(cond)) {                                  \

@@ -596,6 +596,177 @@ int dispatch_gcn2(const GcnParams& p, hipStream_t st) {
     return launch_gcn2<CIP, 2, 2>(p, st);
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Third form: the wide layers (Ci or Co > 64: the C = 128 / 256 blocks of the original ST-GCN schedule that
+// the reference leaves commented out, classifier.py:42-49; north_star's MFMA bench layers).  W no longer fits
+// registers, and at 3*Ci*Co*4 bytes not LDS either, so a block owns ONE output-channel group of COG = 16*COT
+// channels (blockIdx.y) with that slice of W (and of the residual conv's Wr, as a 4th "partition" whose adjacency
+// is the identity) in LDS, and every wave walks frames on its own (no barriers in the loop), all products on
+// v_mfma_f32_16x16x4_f32 with one frame as the column tile:
+//   z_k[ci,w]  = SUM_v x[ci,t,v] A_k[v,w]     A[i=ci][q] = component e of the lane's float4 x[ci][t][4q..4q+3],
+//                                             B[q][j=w] = A_k[4q+e][w] (registers); D reg r of lane (q,w) = z_k[4q+r][w]
+//   y[c,w]    += SUM_ci W_k[c,ci] z_k[ci,w]   A[i=c][q] = W_k[c][16*tile + 4q + r] (LDS), B = D register r of z_k as it lies
+// The aggregation is recomputed per output group (1 / COT of the main product's MFMAs).
+template <int COT>
+__global__ __launch_bounds__(512, 2) void gcn_fwd16_kernel(GcnParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int CIT = p.Ci / 16;
+    const int NP = p.res_w ? 4 : 3;
+    float* Wl = smem;                                   // [NP][CIT][4 r][64 lanes][COT]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = lane >> 4, l16 = lane & 15;
+    const int co0 = blockIdx.y * 16 * COT;
+
+    for (int e = tid; e < NP * CIT * 4 * 64 * COT; e += 512) {
+        const int ct = e % COT, ln = (e / COT) & 63, r = (e / (COT * 64)) & 3, tile = (e / (COT * 256)) % CIT,
+                  kk = e / (COT * 256 * CIT);
+        const int c = co0 + 16 * ct + (ln & 15), ci = 16 * tile + 4 * (ln >> 4) + r;
+        float v = 0.f;
+        if (kk < 3) {
+            if (kk < p.K)
+                v = p.w_transposed ? p.w[(size_t)ci * (p.K * p.Co) + kk * p.Co + c] : p.w[((size_t)kk * p.Co + c) * p.Ci + ci];
+        } else {
+            v = p.res_transposed ? p.res_w[(size_t)ci * p.Co + c] : p.res_w[(size_t)c * p.Ci + ci];
+        }
+        Wl[e] = v;
+    }
+    // B operand of the aggregation: A_k[v = 4q + e][w = l16]; the residual's "adjacency" is the identity
+    float akb[4][4];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) akb[k][e] = (k < p.K) ? p.A[(k * 16 + 4 * q + e) * 16 + l16] : 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) akb[3][e] = (4 * q + e == l16) ? 1.f : 0.f;
+    // bias term of this lane's outputs: c = co0 + 16 ct + 4 q + r, w = l16
+    float bt[COT][4], brs[COT][4];
+#pragma unroll
+    for (int ct = 0; ct < COT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int c = co0 + 16 * ct + 4 * q + r;
+            float s = 0.f;
+            if (p.b)
+                for (int k = 0; k < p.K; ++k) {
+                    float cs = 0.f;
+                    for (int v = 0; v < 16; ++v) cs += p.A[(k * 16 + v) * 16 + l16];
+                    s += p.b[k * p.Co + c] * cs;
+                }
+            bt[ct][r] = s;
+            brs[ct][r] = (p.res_w && p.res_b) ? p.res_b[c] : 0.f;
+        }
+    __syncthreads();
+
+    const long long R = (long long)p.N * p.T;
+    const long long nw = (long long)gridDim.x * 8, gw = (long long)blockIdx.x * 8 + wave;
+    const long long r0 = R * gw / nw, r1 = R * (gw + 1) / nw;
+    const int nrows = (int)(r1 - r0);
+    int n = (int)(r0 / p.T), t = (int)(r0 - (long long)n * p.T);
+    const unsigned TS = (unsigned)p.T * 64u, TOS = (unsigned)p.To * 64u;
+    const unsigned lane_x = (unsigned)l16 * TS + q * 16u;                      // float4 of channel l16 (+16 tile)
+    const unsigned lane_y = (unsigned)(co0 + 4 * q) * TS + l16 * 4u;           // dword of channel co0 + 4q (+16 ct + r)
+    const unsigned lane_r = (unsigned)(co0 + 4 * q) * TOS + l16 * 4u;
+    const float* wl = Wl + (size_t)lane * COT;
+
+    for (int i = 0; i < nrows; ++i) {
+        const bool res_row = p.res_w && (p.stride == 1 || (t & 1) == 0);
+        const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x + (size_t)n * p.Ci * p.T * 16);
+        const unsigned so = (unsigned)t * 64u;
+        f32x4 acc[COT], accr[COT];
+#pragma unroll
+        for (int ct = 0; ct < COT; ++ct) { acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f}; accr[ct] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        f32x4 xq = bload4(rx, lane_x, so);
+        for (int tile = 0; tile < CIT; ++tile) {
+            const f32x4 xc = xq;
+            if (tile + 1 < CIT) xq = bload4(rx, lane_x, so + (unsigned)(tile + 1) * 16u * TS);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (k == 3 && !res_row) break;
+                f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) z = __builtin_amdgcn_mfma_f32_16x16x4f32(xc[e], akb[k][e], z, 0, 0, 0);
+                const float* wk = wl + (size_t)((k * CIT + tile) * 4) * 64 * COT;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float wf[COT];
+                    if constexpr (COT == 8) {
+                        const f32x4 a = *reinterpret_cast<const f32x4*>(wk + (size_t)r * 64 * COT);
+                        const f32x4 b = *reinterpret_cast<const f32x4*>(wk + (size_t)r * 64 * COT + 4);
+                        wf[0] = a[0]; wf[1] = a[1]; wf[2] = a[2]; wf[3] = a[3]; wf[4] = b[0]; wf[5] = b[1]; wf[6] = b[2]; wf[7] = b[3];
+                    } else if constexpr (COT == 4) {
+                        const f32x4 a = *reinterpret_cast<const f32x4*>(wk + (size_t)r * 64 * COT);
+                        wf[0] = a[0]; wf[1] = a[1]; wf[2] = a[2]; wf[3] = a[3];
+                    } else {
+                        wf[0] = wk[(size_t)r * 64 * COT]; wf[1] = wk[(size_t)r * 64 * COT + 1];
+                    }
+                    if (k < 3) {
+#pragma unroll
+                        for (int ct = 0; ct < COT; ++ct)
+                            acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[ct], z[r], acc[ct], 0, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int ct = 0; ct < COT; ++ct)
+                            accr[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[ct], z[r], accr[ct], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        const __amdgpu_buffer_rsrc_t ry = make_rsrc(p.y + (size_t)n * p.Co * p.T * 16);
+#pragma unroll
+        for (int ct = 0; ct < COT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bstore(ry, lane_y, so + (unsigned)(16 * ct + r) * TS, acc[ct][r] + bt[ct][r]);
+        if (res_row) {
+            const __amdgpu_buffer_rsrc_t rr = make_rsrc(p.res_out + (size_t)n * p.Co * p.To * 16);
+            const unsigned sr = (unsigned)(p.stride == 1 ? t : t >> 1) * 64u;
+#pragma unroll
+            for (int ct = 0; ct < COT; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) bstore(rr, lane_r, sr + (unsigned)(16 * ct + r) * TOS, accr[ct][r] + brs[ct][r]);
+        }
+        if (++t == p.T) { t = 0; ++n; }
+    }
+}
+
+// output-channel group of a wide launch: the largest of 128 / 64 / 32 that divides Co and whose W slice fits LDS
+int gcn16_cog(int Ci, int Co, bool res) {
+    const int np = res ? 4 : 3;
+    for (int cog = 128; cog >= 32; cog >>= 1)
+        if (Co % cog == 0 && (size_t)np * Ci * cog * 4 <= 144 * 1024) return cog;
+    return 0;
+}
+
+int launch_gcn16(const GcnParams& p, hipStream_t st) {
+    const int cog = gcn16_cog(p.Ci, p.Co, p.res_w != nullptr);
+    if (!cog) {
+        step::set_error("step_gcn_fwd: no wide kernel for Ci=%d Co=%d", p.Ci, p.Co);
+        return STEP_ERR_ARG;
+    }
+    const size_t lds = (size_t)(p.res_w ? 4 : 3) * p.Ci * cog * 4;
+    const long long rows = (long long)p.N * p.T;
+    long long b = (rows + 15) / 16;
+    const int groups = p.Co / cog;
+    const long long cap = 256 / groups > 0 ? 256 / groups : 1;      // ~one 512-thread block per CU over all groups
+    b = b < 1 ? 1 : (b > cap ? cap : b);
+    auto go = [&](auto kern) {
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) {
+                step::set_error("step_gcn_fwd: hipFuncSetAttribute(%zu): %s", lds, hipGetErrorString(e));
+                return (int)STEP_ERR_LAUNCH;
+            }
+        }
+        hipLaunchKernelGGL(kern, dim3((unsigned)b, groups), dim3(512), lds, st, p);
+        return step::check_launch("step_gcn_fwd(wide)");
+    };
+    if (cog == 128) return go(gcn_fwd16_kernel<8>);
+    if (cog == 64) return go(gcn_fwd16_kernel<4>);
+    return go(gcn_fwd16_kernel<2>);
+}
+
 }  // namespace
 
 extern "C" int step_gcn_fwd(const float* x, const float* in_scale, const float* in_shift,
@@ -607,7 +778,11 @@ extern "C" int step_gcn_fwd(const float* x, const float* in_scale, const float* 
     STEP_REQUIRE(N > 0 && Ci > 0 && Co > 0 && T > 0, "step_gcn_fwd: bad shape N=%d Ci=%d Co=%d T=%d", N,
                  Ci, Co, T);
     STEP_REQUIRE(K >= 1 && K <= 3, "step_gcn_fwd: K=%d partitions (1..3 supported)", K);
-    STEP_REQUIRE(Co <= 64 && Ci <= 64, "step_gcn_fwd: Ci=%d Co=%d > 64 not built (the reference uses 3/32/64)", Ci, Co);
+    // the frame-per-wave form also wins at 64 -> 64 (block 2: 2.62 -> 2.22 ms at N = 4096: a quarter of the main
+    // product's MFMAs go to the aggregation instead of half); 32 -> 64 stays with the second form (3.16 vs 3.28 ms)
+    const bool wide = Ci > 64 || Co > 64 || (Ci == 64 && Co == 64 && !in_scale && !getenv("STEP_GCN_FWD_V1"));
+    STEP_REQUIRE(!wide || (Ci % 16 == 0 && Co % 32 == 0 && Ci <= 256 && Co <= 256 && !in_scale),
+                 "step_gcn_fwd: wide layers need Ci %% 16 == 0, Co %% 32 == 0, both <= 256, no data_bn (Ci=%d Co=%d)", Ci, Co);
     STEP_REQUIRE(stride == 1 || stride == 2, "step_gcn_fwd: stride %d", stride);
     STEP_REQUIRE(a_nnz_max >= 1 && a_nnz_max <= 16, "step_gcn_fwd: a_nnz_max=%d", a_nnz_max);
     STEP_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "step_gcn_fwd: in_scale/in_shift pair");
@@ -623,6 +798,7 @@ extern "C" int step_gcn_fwd(const float* x, const float* in_scale, const float* 
     STEP_REQUIRE(nt <= 0x7fffffffLL, "step_gcn_fwd: too many tiles");
     p.ntiles = (int)nt;
     hipStream_t st = (hipStream_t)stream;
+    if (wide) return launch_gcn16(p, st);
     const int mt = p.Copad / 32;
     if (!in_scale && (Ci == 32 || Ci == 64) && !getenv("STEP_GCN_FWD_V1")) {
         const int rc = Ci == 32 ? dispatch_gcn2<32>(p, st) : dispatch_gcn2<64>(p, st);

@@ -649,22 +649,6 @@ __device__ __forceinline__ void lds_frag(const float* p, float (&out)[CT]) {
     }
 }
 
-// raw buffer access: descriptor (uniform base) + 32-bit lane offset + uniform SGPR offset - no 64-bit VALU address
-// arithmetic per access (it would all add to the MFMA time: fp32 MFMAs and the same wave's VALU do not overlap)
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base) {
-    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7ffffffc, 0x00020000);
-}
-__device__ __forceinline__ float bload(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
-}
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ f32x4 bload4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
-}
-__device__ __forceinline__ void bstore(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float v) {
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)voff, (int)soff, 0);
-}
-
 // acc += c * (src rotated right by R lanes inside its row of 16) as ONE instruction.  hipcc leaves
 // __builtin_amdgcn_mov_dpp + fmaf as v_mov_b32_dpp + (SLP-packed) v_pk_fma_f32 - twice the VALU work, and every VALU
 // cycle of this wave adds to its fp32 MFMA time.  `first` pads the SALU-writes-EXEC -> DPP hazard (5 wait states)
@@ -889,12 +873,192 @@ __global__ __launch_bounds__(512, 2) void gcn_bwd_data16_kernel(GbParams p) {
     }
 }
 
-// weight kernel: 512-thread blocks = 8 waves = (CI / 16 input-channel tiles) x (8 / CIT frame streams)
+// Data kernel of the wide layers: a block owns a group of CIG = 16 * CT input channels (blockIdx.y) with the matching
+// slice of W (all Co output channels) in LDS and walks the output channels in chunks of 64, so dz for its group stays
+// in 12 * CT registers whatever Co is.  Otherwise gcn_bwd_data16_kernel: one frame per wave at a time, no barriers.
+template <int CT>
+__global__ __launch_bounds__(512, 2) void gcn_bwd_data16w_kernel(GbParams p) {
+    constexpr int S = 16;                             // k-steps of one 64-channel chunk
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int CO = p.Co, CI = p.Ci, NCH = CO / 64;
+    const bool has_res = p.dres != nullptr;
+    float* Wl = smem;                                 // [3][CO / 4][64 lanes][CT]
+    float* Wrl = Wl + 3 * (CO / 4) * 64 * CT;         // [CO / 4][64][CT]   (residual)
+    float* cfs = Wrl + (has_res ? (CO / 4) * 64 * CT : 0);   // [3][16 joints][16 rotations]
+    float* red = smem;                                // [8][768], after the loop
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = lane >> 4, l16 = lane & 15;
+    const int ci0 = blockIdx.y * 16 * CT;
+
+    for (int e = tid; e < 3 * (CO / 4) * 64 * CT; e += 512) {
+        const int tile = e % CT, ln = (e / CT) & 63, s = (e / (CT * 64)) % (CO / 4), k = e / (CT * 64 * (CO / 4));
+        const int c = 4 * s + (ln >> 4), ci = ci0 + 16 * tile + (ln & 15);
+        float v = 0.f;
+        if (k < p.K)
+            v = p.w_transposed ? p.w[(size_t)ci * (p.K * CO) + k * CO + c] : p.w[((size_t)k * CO + c) * CI + ci];
+        Wl[e] = v;
+    }
+    if (has_res) {
+        for (int e = tid; e < (CO / 4) * 64 * CT; e += 512) {
+            const int tile = e % CT, ln = (e / CT) & 63, s = e / (CT * 64);
+            const int c = 4 * s + (ln >> 4), ci = ci0 + 16 * tile + (ln & 15);
+            Wrl[e] = p.res_transposed ? p.res_w[(size_t)ci * CO + c] : p.res_w[(size_t)c * CI + ci];
+        }
+    }
+    unsigned rmask[3] = {0u, 0u, 0u};
+    static_for<0, 16>([&](auto rt) {
+        constexpr int R = decltype(rt)::value;
+        const int src = __float_as_int(row_ror<R>(__int_as_float(l16)));
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float a = (k < p.K) ? p.A[(k * 16 + l16) * 16 + src] : 0.f;
+            if (tid < 16) cfs[(k * 16 + l16) * 16 + R] = a;
+            if (__ballot(a != 0.f) != 0ull) rmask[k] |= 1u << R;
+        }
+    });
+#pragma unroll
+    for (int k = 0; k < 3; ++k) rmask[k] = __builtin_amdgcn_readfirstlane(rmask[k]);
+    __syncthreads();
+
+    f32x4 dAk[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) dAk[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const long long R = (long long)p.N * p.T;
+    const long long nw = (long long)gridDim.x * 8, gw = (long long)blockIdx.x * 8 + wave;
+    const long long r0 = R * gw / nw, r1 = R * (gw + 1) / nw;
+    const int nrows = (int)(r1 - r0);
+    const unsigned TS = (unsigned)p.T * 64u, TOS = (unsigned)p.To * 64u;
+    const unsigned lane_dy = (unsigned)q * TS + l16 * 4u, lane_x = (unsigned)(ci0 + 4 * q) * TS + l16 * 4u;
+    const unsigned lane_dr = (unsigned)q * TOS + l16 * 4u;
+    int n = (int)(r0 / p.T), t = (int)(r0 - (long long)n * p.T);
+    const float* wl = Wl + (size_t)lane * CT;
+    const float* wr = Wrl + (size_t)lane * CT;
+
+    for (int i = 0; i < nrows; ++i) {
+        const bool res_row = has_res && (p.stride == 1 || (t & 1) == 0);
+        const unsigned so = (unsigned)t * 64u;
+        const __amdgpu_buffer_rsrc_t rdy = make_rsrc(p.dy + (size_t)n * CO * p.T * 16);
+        const __amdgpu_buffer_rsrc_t rdr = make_rsrc(has_res ? p.dres + (size_t)n * CO * p.To * 16 : p.dy);
+        const unsigned sr = (unsigned)(p.stride == 1 ? t : t >> 1) * 64u;
+        float xc[CT * 4];
+        {
+            const __amdgpu_buffer_rsrc_t rs = make_rsrc(p.x + (size_t)n * CI * p.T * 16);
+#pragma unroll
+            for (int j = 0; j < CT * 4; ++j) xc[j] = bload(rs, lane_x, so + (unsigned)((j >> 2) * 16 + (j & 3)) * TS);
+        }
+        f32x4 dz[3][CT], dxa[CT];
+#pragma unroll
+        for (int j = 0; j < CT; ++j) {
+            dxa[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 3; ++k) dz[k][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        float dyc[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) dyc[s] = bload(rdy, lane_dy, so + (unsigned)s * 4u * TS);
+        for (int ch = 0; ch < NCH; ++ch) {
+            float dyn[S], drc[S];
+            if (ch + 1 < NCH) {
+#pragma unroll
+                for (int s = 0; s < S; ++s) dyn[s] = bload(rdy, lane_dy, so + (unsigned)(16 * (ch + 1) + s) * 4u * TS);
+            }
+            if (res_row) {
+#pragma unroll
+                for (int s = 0; s < S; ++s) drc[s] = bload(rdr, lane_dr, sr + (unsigned)(16 * ch + s) * 4u * TOS);
+            }
+#pragma unroll
+            for (int s = 0; s < S; ++s)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    float wf[CT];
+                    lds_frag<CT>(wl + (size_t)(k * (CO / 4) + 16 * ch + s) * 64 * CT, wf);
+#pragma unroll
+                    for (int j = 0; j < CT; ++j)
+                        dz[k][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[j], dyc[s], dz[k][j], 0, 0, 0);
+                }
+            if (res_row) {
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    float wv[CT];
+                    lds_frag<CT>(wr + (size_t)(16 * ch + s) * 64 * CT, wv);
+#pragma unroll
+                    for (int j = 0; j < CT; ++j)
+                        dxa[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[j], drc[s], dxa[j], 0, 0, 0);
+                }
+            }
+            if (ch + 1 < NCH) {
+#pragma unroll
+                for (int s = 0; s < S; ++s) dyc[s] = dyn[s];
+            }
+        }
+        f32x4 cf[3][4];
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) cf[k][g] = *reinterpret_cast<const f32x4*>(cfs + (k * 16 + l16) * 16 + 4 * g);
+#pragma unroll
+        for (int j = 0; j < CT; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+                    dAk[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(xc[j * 4 + r], dz[k][j][r], dAk[k], 0, 0, 0);
+        if (p.dx) {
+            float dxr[CT * 4];
+#pragma unroll
+            for (int j = 0; j < CT; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dxr[j * 4 + r] = dxa[j][r];
+            __builtin_amdgcn_sched_barrier(0);
+            static_for<0, 3>([&](auto kt) {
+                constexpr int kq = decltype(kt)::value;
+                static_for<0, 16>([&](auto rt) {
+                    constexpr int RR = decltype(rt)::value;
+                    if ((rmask[kq] >> RR) & 1u) {
+                        const float c = cf[kq][RR >> 2][RR & 3];
+#pragma unroll
+                        for (int j = 0; j < CT; ++j)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                fma_ror<RR>(dxr[j * 4 + r], c, dz[kq][j][r], j == 0 && r == 0);
+                    }
+                });
+            });
+            const __amdgpu_buffer_rsrc_t rs = make_rsrc(p.dx + (size_t)n * CI * p.T * 16);
+#pragma unroll
+            for (int j = 0; j < CT * 4; ++j) bstore(rs, lane_x, so + (unsigned)((j >> 2) * 16 + (j & 3)) * TS, dxr[j]);
+        }
+        if (++t == p.T) { t = 0; ++n; }
+    }
+
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) red[wave * 768 + (k * 16 + 4 * q + i) * 16 + l16] = dAk[k][i];
+    __syncthreads();
+    for (int e = tid; e < 768; e += 512) {
+        float sum = 0.f;
+#pragma unroll
+        for (int w8 = 0; w8 < 8; ++w8) sum += red[w8 * 768 + e];
+        p.part1[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 768 + e] = sum;
+    }
+}
+
+// weight kernel: 512-thread blocks = 8 waves = (CI / 16 input-channel tiles) x (8 / CIT frame streams).  CI / CO are
+// the channels ONE BLOCK covers: wide layers (Ci or Co > 64) run as blockIdx.y = (input group, output group) with the
+// same code, each group writing its own sub-block of the partial row.
 template <int CI, int CO>
 __global__ __launch_bounds__(512, 2) void gcn_bwd_weight16_kernel(GbParams p) {
     constexpr int CIT = CI / 16, COT = CO / 16;
     constexpr int SPB = 8 / CIT;                      // frame streams per block (waves sharing a ci tile)
-    constexpr int PART = 3 * CO * CI + CO * 16 + CO * CI + CO;
+    const int CIA = p.Ci, COA = p.Co;                 // all channels
+    const int PART = 3 * COA * CIA + COA * 16 + COA * CIA + COA;
+    const int ngi = CIA / CI;
+    const int ci0 = ((int)blockIdx.y % ngi) * CI, co0 = ((int)blockIdx.y / ngi) * CO;
     constexpr int PW = (4 * COT) * 4 + 2 * COT * 4;   // accumulator floats per lane
     extern __shared__ __attribute__((aligned(16))) float smem[];   // [SPB - 1][CIT][64][PW]: the other streams' sums
 
@@ -927,19 +1091,19 @@ __global__ __launch_bounds__(512, 2) void gcn_bwd_weight16_kernel(GbParams p) {
     const int nrows = (int)(r1 - r0);
     const bool have_res = p.dres != nullptr;
     const unsigned TS = (unsigned)p.T * 64u, TOS = (unsigned)p.To * 64u;
-    const unsigned lane_x = (unsigned)(16 * cit + l16) * TS + q * 16u;
-    const unsigned lane_dy = (unsigned)l16 * TS + q * 16u, lane_dr = (unsigned)l16 * TOS + q * 16u;
+    const unsigned lane_x = (unsigned)(ci0 + 16 * cit + l16) * TS + q * 16u;
+    const unsigned lane_dy = (unsigned)(co0 + l16) * TS + q * 16u, lane_dr = (unsigned)(co0 + l16) * TOS + q * 16u;
     int n = (int)(r0 / p.T), t = (int)(r0 - (long long)n * p.T);
 
     struct Row { f32x4 x, dy[COT], dr[COT]; };
     auto load_row = [&](int nn, int tt, Row& rw) {
         const unsigned so = (unsigned)tt * 64u;
-        rw.x = bload4(make_rsrc(p.x + (size_t)nn * CI * p.T * 16), lane_x, so);
-        const __amdgpu_buffer_rsrc_t rs = make_rsrc(p.dy + (size_t)nn * CO * p.T * 16);
+        rw.x = bload4(make_rsrc(p.x + (size_t)nn * CIA * p.T * 16), lane_x, so);
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(p.dy + (size_t)nn * COA * p.T * 16);
 #pragma unroll
         for (int ct = 0; ct < COT; ++ct) rw.dy[ct] = bload4(rs, lane_dy, so + (unsigned)ct * 16u * TS);
         if (have_res && (p.stride == 1 || (tt & 1) == 0)) {
-            const __amdgpu_buffer_rsrc_t rr = make_rsrc(p.dres + (size_t)nn * CO * p.To * 16);
+            const __amdgpu_buffer_rsrc_t rr = make_rsrc(p.dres + (size_t)nn * COA * p.To * 16);
             const unsigned sr = (unsigned)(p.stride == 1 ? tt : tt >> 1) * 64u;
 #pragma unroll
             for (int ct = 0; ct < COT; ++ct) rw.dr[ct] = bload4(rr, lane_dr, sr + (unsigned)ct * 16u * TOS);
@@ -961,7 +1125,7 @@ __global__ __launch_bounds__(512, 2) void gcn_bwd_weight16_kernel(GbParams p) {
         }
 #pragma unroll
         for (int ct = 0; ct < COT; ++ct) {
-            if (cit == 0) Sacc[ct] += cur.dy[ct];
+            if (cit == 0 && ci0 == 0) Sacc[ct] += cur.dy[ct];
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -971,7 +1135,7 @@ __global__ __launch_bounds__(512, 2) void gcn_bwd_weight16_kernel(GbParams p) {
         if (have_res && (p.stride == 1 || (tt & 1) == 0)) {
 #pragma unroll
             for (int ct = 0; ct < COT; ++ct) {
-                if (cit == 0) Bacc[ct] += cur.dr[ct];
+                if (cit == 0 && ci0 == 0) Bacc[ct] += cur.dr[ct];
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     accr[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.dr[ct][r], cur.x[r], accr[ct], 0, 0, 0);
@@ -1017,24 +1181,24 @@ __global__ __launch_bounds__(512, 2) void gcn_bwd_weight16_kernel(GbParams p) {
             }
         }
         float* part = p.part2 + (size_t)blockIdx.x * PART;
-        const int ci = 16 * cit + l16;
+        const int ci = ci0 + 16 * cit + l16;
 #pragma unroll
         for (int ct = 0; ct < COT; ++ct) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int c = 16 * ct + 4 * q + r;
+                const int c = co0 + 16 * ct + 4 * q + r;
 #pragma unroll
-                for (int k = 0; k < 3; ++k) part[(k * CO + c) * CI + ci] = acc[k][ct][r];
-                part[3 * CO * CI + CO * 16 + c * CI + ci] = accr[ct][r];
+                for (int k = 0; k < 3; ++k) part[(k * COA + c) * CIA + ci] = acc[k][ct][r];
+                part[3 * COA * CIA + COA * 16 + c * CIA + ci] = accr[ct][r];
             }
-            if (cit == 0) {
-                const int c = 16 * ct + l16;                      // the lane's dy row
-                float* ps = part + 3 * CO * CI + c * 16 + 4 * q;
+            if (cit == 0 && ci0 == 0) {
+                const int c = co0 + 16 * ct + l16;                // the lane's dy row
+                float* ps = part + 3 * COA * CIA + c * 16 + 4 * q;
                 ps[0] = Sacc[ct][0]; ps[1] = Sacc[ct][1]; ps[2] = Sacc[ct][2]; ps[3] = Sacc[ct][3];
                 float b = (Bacc[ct][0] + Bacc[ct][1]) + (Bacc[ct][2] + Bacc[ct][3]);
                 b += __shfl_xor(b, 16, 64);
                 b += __shfl_xor(b, 32, 64);
-                if (q == 0) part[3 * CO * CI + CO * 16 + CO * CI + c] = b;
+                if (q == 0) part[3 * COA * CIA + COA * 16 + COA * CIA + c] = b;
             }
         }
     }
@@ -1169,6 +1333,60 @@ bool gb16_shape(int Ci, int Co, const float* in_scale) {
     return !in_scale && (Ci == 32 || Ci == 64) && (Co == 32 || Co == 64) && !getenv("STEP_GCN_BWD_V1");
 }
 
+// wide layers (Ci or Co > 64): channel groups per launch
+struct Gb16w { int ct, gi1, cib, cob, gy2, nblk; size_t lds1; };
+bool gb16w_geom(int N, int Ci, int Co, int T, bool res, Gb16w* g) {
+    if (Ci % 32 || Co % 64 || Ci > 256 || Co > 256 || Ci < 32 || (Ci <= 64 && Co <= 64)) return false;
+    // data kernel: input-channel group of 64 or 32 whose W slice (all Co) fits LDS
+    g->ct = 0;
+    for (int ct = 4; ct >= 2; ct >>= 1) {
+        const size_t lds = ((size_t)(3 + (res ? 1 : 0)) * Co * 16 * ct + 768) * 4;
+        if (Ci % (16 * ct) == 0 && lds <= 150 * 1024) { g->ct = ct; g->lds1 = lds < 8 * 768 * 4 ? 8 * 768 * 4 : lds; break; }
+    }
+    if (!g->ct) return false;
+    g->gi1 = Ci / (16 * g->ct);
+    g->cib = Ci % 128 == 0 ? 128 : 64;
+    g->cob = 64;
+    g->gy2 = (Ci / g->cib) * (Co / g->cob);
+    const long long rows = (long long)N * T;
+    long long b = (rows + 15) / 16;
+    const int gmax = g->gi1 > g->gy2 ? g->gi1 : g->gy2;
+    const long long cap = 512 / gmax > 0 ? 512 / gmax : 1;
+    g->nblk = (int)(b < 1 ? 1 : (b > cap ? cap : b));
+    return true;
+}
+
+int launch_gb16w(const GbParams& p, const Gb16w& g, hipStream_t st) {
+    hipError_t e = hipSuccess;
+    auto attr = [&](const void* k, size_t lds) {
+        if (e == hipSuccess && lds > 64 * 1024)
+            e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    };
+    if (g.ct == 4) {
+        attr(reinterpret_cast<const void*>(gcn_bwd_data16w_kernel<4>), g.lds1);
+        if (e == hipSuccess) hipLaunchKernelGGL((gcn_bwd_data16w_kernel<4>), dim3(g.nblk, g.gi1), dim3(512), g.lds1, st, p);
+    } else {
+        attr(reinterpret_cast<const void*>(gcn_bwd_data16w_kernel<2>), g.lds1);
+        if (e == hipSuccess) hipLaunchKernelGGL((gcn_bwd_data16w_kernel<2>), dim3(g.nblk, g.gi1), dim3(512), g.lds1, st, p);
+    }
+    if (e != hipSuccess) {
+        step::set_error("step_gcn_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        return STEP_ERR_LAUNCH;
+    }
+    if (g.cib == 128) {
+        hipLaunchKernelGGL((gcn_bwd_weight16_kernel<128, 64>), dim3(g.nblk, g.gy2), dim3(512), 16, st, p);
+    } else {
+        const size_t lds2 = (size_t)4 * 64 * 96 * 4;       // two frame streams per ci tile: see launch_gb16
+        attr(reinterpret_cast<const void*>(gcn_bwd_weight16_kernel<64, 64>), lds2);
+        if (e != hipSuccess) {
+            step::set_error("step_gcn_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
+            return STEP_ERR_LAUNCH;
+        }
+        hipLaunchKernelGGL((gcn_bwd_weight16_kernel<64, 64>), dim3(g.nblk, g.gy2), dim3(512), lds2, st, p);
+    }
+    return step::check_launch("step_gcn_bwd(wide)");
+}
+
 int gb16_blocks(int N, int T) {
     const long long rows = (long long)N * T;
     const long long b = (rows + 15) / 16;             // 8 waves per block, at least two frames per wave
@@ -1251,6 +1469,13 @@ int dispatch_gb(const GbParams& p, const GbGeom& g, hipStream_t st) {
 extern "C" size_t step_gcn_bwd_ws_bytes(int N, int Ci, int Co, int K, int T) {
     (void)K;
     size_t best = 0;
+    {
+        Gb16w gw;                                                                      // wide layers
+        if (N >= 1 && T >= 1 && gb16w_geom(N, Ci, Co, T, true, &gw)) {
+            const size_t part2 = 3 * (size_t)Co * Ci + (size_t)Co * 16 + (size_t)Co * Ci + Co;
+            return (((size_t)gw.nblk * gw.gi1 + 1) * 768 + ((size_t)gw.nblk + 1) * part2) * 4;
+        }
+    }
     if ((Ci == 32 || Ci == 64) && (Co == 32 || Co == 64) && N >= 1 && T >= 1) {      // second form
         const size_t nb = (size_t)gb16_blocks(N, T);
         best = (nb + 1) * ((size_t)768 + 3 * (size_t)Co * Ci + (size_t)Co * 16 + (size_t)Co * Ci + Co) * 4;
@@ -1276,11 +1501,22 @@ extern "C" int step_gcn_bwd(const float* dy, const float* dres, const float* x, 
     STEP_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "step_gcn_bwd: in_scale/in_shift pair");
     STEP_REQUIRE((dres == nullptr) == (res_w == nullptr), "step_gcn_bwd: dres and res_w come together");
     GbGeom g;
-    STEP_REQUIRE(gb_geom(N, Ci, Co, T, a_nnz_max, &g), "step_gcn_bwd: unsupported N=%d Ci=%d Co=%d T=%d", N,
-                 Ci, Co, T);
-    const bool v2 = gb16_shape(Ci, Co, in_scale);
+    Gb16w gw;
+    const bool wide = N >= 1 && T >= 1 && !in_scale && gb16w_geom(N, Ci, Co, T, true, &gw);
+    if (wide) {
+        g = GbGeom{};
+        g.emax = 16;
+    } else {
+        STEP_REQUIRE(gb_geom(N, Ci, Co, T, a_nnz_max, &g), "step_gcn_bwd: unsupported N=%d Ci=%d Co=%d T=%d", N,
+                     Ci, Co, T);
+    }
+    const bool v2 = wide || gb16_shape(Ci, Co, in_scale);
+    if (wide) {
+        g.nblk1 = gw.nblk * gw.gi1;
+        g.nblk2 = gw.nblk;
+    }
     if (v2) {
-        g.nblk1 = g.nblk2 = gb16_blocks(N, T);
+        if (!wide) g.nblk1 = g.nblk2 = gb16_blocks(N, T);
         g.copad = Co; g.cir = Ci;
         g.part1 = 768;
         g.part2 = 3 * (size_t)Co * Ci + (size_t)Co * 16 + (size_t)Co * Ci + Co;
@@ -1312,7 +1548,7 @@ extern "C" int step_gcn_bwd(const float* dy, const float* dres, const float* x, 
     p.tiles_per_seq = (T + TT - 1) / TT;
     p.ntiles = N * p.tiles_per_seq;
     hipStream_t st = (hipStream_t)stream;
-    int rc = v2 ? dispatch_gb16(p, g.nblk1, st) : dispatch_gb(p, g, st);
+    int rc = wide ? launch_gb16w(p, gw, st) : (v2 ? dispatch_gb16(p, g.nblk1, st) : dispatch_gb(p, g, st));
     if (rc) return rc;
     float* tot1 = p.part2 + (size_t)g.nblk2 * g.part2;   // (workspace rows: nblk1_ws + nblk2 + 2)
     float* tot2 = tot1 + g.part1;

@@ -49,7 +49,8 @@ def test_shape_errors_are_reported_before_launch():
                          1, 3, 3, 10, 10, 75, 1, 0, None)
     assert rc == -1 and b"null pointer" in l.step_last_error()
     rc = l.step_gcn_fwd(1, None, None, 1, None, 0, 1, 4, 1, None, None, 0, None, 2, 3, 128, 3, 10, 1, None)
-    assert rc == -1 and b"Co=128" in l.step_last_error()
+    assert rc == -1 and b"Co=128" in l.step_last_error()          # wide layers need Ci % 16 == 0
+    assert l.step_gcn_bwd_ws_bytes(64, 128, 256, 3, 60) > 0
 
 
 def test_models_keep_reference_state_dict_contract():

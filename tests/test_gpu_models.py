@@ -429,3 +429,60 @@ def test_second_gpu_without_set_device():
         assert torch.equal(a.cpu(), b.cpu())
         with pytest.raises(StepHipError, match="different devices"):
             m1(x.to(D))
+
+
+@pytest.mark.parametrize("cin,cout,stride,T,N", [(64, 128, 2, 21, 3), (128, 128, 1, 13, 2), (128, 256, 2, 16, 2),
+                                                 (256, 256, 1, 9, 2)])
+@pytest.mark.parametrize("mode", ["train", "eval"])
+def test_wide_st_gcn_block_vs_oracle(cin, cout, stride, T, N, mode):
+    """The 128 / 256-channel st_gcn blocks of the original ST-GCN schedule that the reference leaves commented out
+    (classifier.py:42-49; north_star's MFMA bench layers): a whole block - wide graph conv + residual conv, BN,
+    wide temporal conv, BN, add, ReLU - forward and backward against the oracle's st_gcn_block (no reference
+    fixture can exist for them: the reference never builds these widths)."""
+    from step_amd.net.blocks import st_gcn
+    from step_amd.net.utils.graph import Graph
+    torch.manual_seed(cin + cout + stride)
+    blk = st_gcn(cin, cout, (75, 3), stride)
+    with torch.no_grad():
+        for m in blk.modules():
+            if isinstance(m, torch.nn.Conv2d):
+                m.weight.normal_(0.0, 0.05)
+                m.bias.normal_(0.0, 0.1)
+            elif isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.normal_(1.0, 0.1)
+                m.bias.normal_(0.0, 0.1)
+                m.running_mean.normal_(0.0, 0.1)
+                m.running_var.uniform_(0.5, 1.5)
+    P = {"b." + k: v.detach().clone() for k, v in blk.state_dict().items()}
+    A = torch.tensor(Graph(strategy="spatial").A, dtype=torch.float32) * (torch.rand(3, 16, 16) + 0.5)
+    x = torch.randn(N, cin, T, 16)
+    gy_shape = (N, cout, (T - 1) // stride + 1, 16)
+    gy = torch.randn(gy_shape)
+    # oracle
+    leaves = {k: v.clone().requires_grad_(True) for k, v in P.items() if v.is_floating_point() and "running" not in k}
+    Q = dict(P)
+    Q.update(leaves)
+    xo, Ao = x.clone().requires_grad_(True), A.clone().requires_grad_(True)
+    yo = stgcn.st_gcn_block(xo, Ao, Q, "b", stride, True, mode == "train")
+    yo.backward(gy)
+    # product
+    blk = blk.to(D).train(mode == "train")
+    blk.a_nnz_max = 4
+    xg, Ag = x.to(D).requires_grad_(True), A.to(D).requires_grad_(True)
+    yg, _ = blk(xg, Ag)
+    assert_close(yg, yo, 1e-4, "y")
+    yg.backward(gy.to(D))
+    assert_close(xg.grad, xo.grad, 3e-4, "gx")
+    supp = (A != 0).float()
+    assert_close(Ag.grad.cpu() * supp, Ao.grad * supp, 3e-4, "gA")
+    for name, prm in blk.named_parameters():
+        noise = 1e-7 * float(gy.abs().sum()) if (mode == "train" and feeds_train_bn(name)) else 1e-6
+        assert_grad_close(prm.grad, leaves["b." + name].grad, 3e-4, name, noise)
+    if mode == "train":
+        sd = blk.state_dict()
+        for k in ("tcn.0.running_mean", "tcn.0.running_var", "tcn.3.running_mean", "tcn.3.running_var"):
+            assert_grad_close(sd[k], Q["b." + k], 2e-5, k, 1e-7)
+    else:
+        with torch.no_grad():
+            y2, _ = blk(x.to(D), A.to(D))
+        assert_close(y2, yo, 1e-4, "fused eval y")
