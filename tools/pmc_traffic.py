@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""profiles/pmc_traffic.json from the PMC passes of tools/gpu_pmc_wgrad.sh (gpurun_out/pmc_wg_{mfma,fetch,write}.txt),
+run HERE after the gpurun call has merged them back.  bench.py puts `hbm_bytes` of the dominant kernel into
+`roofline.traffic` only while the sha256 of the kernel sources recorded here equals that of the tree it runs
+from - so the number cannot outlive the kernel it was measured on.
+
+  hbm_bytes = 2 * FETCH_SIZE * 1024 + bytes stored      (gfx950: FETCH_SIZE counts half of a wide coalesced read,
+                                                          MI355X_MICROARCH.md; KB units)
+The sliding-window wgrad's WRITE_SIZE equals its FETCH_SIZE (the counter sees the LDS-DMA requests), so its stored
+bytes are taken as what it does store: the per-slice slabs, nsplit * Co * Ci * Kt * 4.
+"""
+import hashlib
+import json
+import os
+import re
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SOURCES = ["step_amd/csrc/tcn_wgrad_sw.hip", "step_amd/csrc/tcn_wgrad.hip", "step_amd/csrc/tcn.hip",
+           "step_amd/csrc/tcn_pack.h", "step_amd/csrc/common.h"]
+LINE = re.compile(r"^(.*?)\s+([A-Z_]+)\s+n=(\d+) mean=([0-9.eE+-]+) mean_dur_ns=(\d+)\s*$")
+N, C, T, S, KT = 4096, 64, 240, 2, 75
+
+
+def read(path):
+    out = {}
+    for line in open(path):
+        m = LINE.match(line.rstrip("\n"))
+        if m:
+            name = m.group(1).replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].strip()
+            out.setdefault(name, {})[m.group(2)] = (float(m.group(4)), int(m.group(5)))
+    return out
+
+
+def main(src="gpurun_out"):
+    mf, fe, wr = (read(os.path.join(ROOT, src, "pmc_wg_%s.txt" % k)) for k in ("mfma", "fetch", "write"))
+    h = hashlib.sha256()
+    for p in SOURCES:
+        h.update(open(os.path.join(ROOT, p), "rb").read())
+    sha = subprocess.run(["git", "-C", ROOT, "rev-parse", "HEAD"], capture_output=True, text=True).stdout.strip()
+    dirty = subprocess.run(["git", "-C", ROOT, "status", "--porcelain", "--"] + SOURCES, capture_output=True, text=True).stdout.strip()
+    tout = (T - 1) // S + 1
+    alg = 4 * N * C * 16 * (T + tout)
+    res = {"_comment": __doc__.strip().split("\n\n")[0], "batch": N, "frames": T, "sources": SOURCES,
+           "source_sha256": h.hexdigest(), "git_sha": sha + ("+dirty" if dirty else ""),
+           "command": "python3 tools/kbench.py all --n 4096 --c 64 --stride 2 --t 240 --reps 1 (tools/gpu_pmc_wgrad.sh)"}
+    for k in sorted(fe):
+        if k not in wr or k not in mf:
+            continue
+        f, dur_f = fe[k]["FETCH_SIZE"]
+        w, dur_w = wr[k]["WRITE_SIZE"]
+        gui, dur_m = mf[k]["GRBM_GUI_ACTIVE"]
+        busy = mf[k]["SQ_VALU_MFMA_BUSY_CYCLES"][0]
+        ent = {"kernel": k, "ms": round((dur_f + dur_w) / 2e6, 3), "FETCH_SIZE_KB": round(f, 1), "WRITE_SIZE_KB": round(w, 1),
+               "mfma_busy": round(busy / 1024 / (gui / 8), 4), "clock_ghz": round(gui / 8 / dur_m, 3),
+               "algorithmic_bytes": alg}
+        if k.startswith("tcn_wgrad_sw_kernel"):
+            stored = 32 * C * C * KT * 4
+            ent["hbm_bytes"] = float("%.4g" % (2 * f * 1024 + stored))
+            res["tcn_wgrad_b1"] = ent
+        elif k.startswith("tcn_conv_kernel"):
+            ent["hbm_bytes"] = float("%.4g" % ((2 * f + w) * 1024))
+            # stride 2: forward = <5, 38, 2, ...>, input gradient = two output phases of 19 taps <5, 19, 1, ...>
+            res["tcn_fwd_b1" if "38, 2" in k else "tcn_dgrad_b1"] = ent
+    json.dump(res, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
+    for k in ("tcn_wgrad_b1", "tcn_fwd_b1", "tcn_dgrad_b1"):
+        if k in res:
+            e = res[k]
+            print("%-14s %-40s %7.3f ms  hbm %.3g B (algorithmic %.3g)  mfma busy %.3f @ %.2f GHz" %
+                  (k, e["kernel"], e["ms"], e["hbm_bytes"], e["algorithmic_bytes"], e["mfma_busy"], e["clock_ghz"]))
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:])
