@@ -1204,6 +1204,240 @@ __global__ __launch_bounds__(512, 2) void gcn_bwd_weight16_kernel(GbParams p) {
     }
 }
 
+// Backward of the FIRST block's graph conv (Ci <= 4: the 3 coordinate channels; data_bn folded into the load,
+// residual 1x1 conv, Co = 32): HBM-bound (dy and dres are 2 GB each at N = 4096), so ONE kernel reads them once
+// for both the data and the weight gradients - the two-kernel forms read everything twice.  Frame-per-wave, operands in
+// registers; the three partitions share one 16-row tile, row 4k + ci:
+//   dz[4k+ci][w]   = SUM_c W_k[c,ci] dy[c,t,w]           A = W (registers),  B = the lane's 4-byte loads of dy
+//   dA_k[v,w]     += SUM_ci x'[ci,v] dz[4k+ci][w]        B = dz's D register where the lane's row group q == k, else 0
+//   dx[ci,v]       = SUM_k SUM_w A_k[v,w] dz[4k+ci][w]   DPP rotations with the lane's OWN partition's coefficients
+//                    (row group q = k), then a sum over the row groups; + Wr^T dres (same layout, rows ci)
+//   z_k[ci,w]      = SUM_v x'[ci,v] A_k[v,w]             lane j of a row holds channel j & 3, so after selecting
+//                    k = j >> 2 the three results form ONE B operand with column j = 4k + ci
+//   dW[c][4k+ci]  += SUM_w dy[c,t,w] z[4k+ci][w],   dWr[c][ci] += SUM_w dres[c,t',w] x'[ci,s t',w]
+// x' = data_bn(x) (scale / shift per (v, ci): per-lane constants in both load layouts).  Every wave writes its own
+// partial row through LDS at the end (ordered sums as everywhere); no barrier inside the frame loop.
+template <int COT>
+__global__ __launch_bounds__(512, 2) void gcn_bwd_small_kernel(GbParams p) {
+    constexpr int CO = 16 * COT, S = CO / 4;
+    constexpr int PART = 3 * CO * 4 + CO * 16 + CO * 4 + CO;       // partial row, Ci padded to 4
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = lane >> 4, l16 = lane & 15;
+    const int Ci = p.Ci;
+    const bool has_res = p.dres != nullptr;
+
+    // A operands held in registers: row i = l16 = 4k + ci of step s: W_k[c = 4s + q][ci]; residual: row i = ci
+    float wreg[S], wrreg[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const int c = 4 * s + q, k = l16 >> 2, ci = l16 & 3;
+        float v = 0.f, vr = 0.f;
+        if (k < p.K && ci < Ci)
+            v = p.w_transposed ? p.w[(size_t)ci * (p.K * CO) + k * CO + c] : p.w[((size_t)k * CO + c) * Ci + ci];
+        if (has_res && l16 < Ci) vr = p.res_transposed ? p.res_w[(size_t)l16 * CO + c] : p.res_w[(size_t)c * Ci + l16];
+        wreg[s] = v;
+        wrreg[s] = vr;
+    }
+    // aggregation: A[i = w][k' = q] of step e = A_k[v = 4q + e][w]
+    float akt[3][4];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) akt[k][e] = (k < p.K) ? p.A[(k * 16 + 4 * q + e) * 16 + l16] : 0.f;
+    // rotation coefficients of the lane's own partition (row group q): A[q][v = l16][w = source lane of row_ror:R]
+    float cfl[16];
+    unsigned rmask = 0u;
+    static_for<0, 16>([&](auto rt) {
+        constexpr int R = decltype(rt)::value;
+        const int src = __float_as_int(row_ror<R>(__int_as_float(l16)));
+        const float a = (q < p.K) ? p.A[(q * 16 + l16) * 16 + src] : 0.f;
+        cfl[R] = a;
+        if (__ballot(a != 0.f) != 0ull) rmask |= 1u << R;
+    });
+    rmask = __builtin_amdgcn_readfirstlane(rmask);
+    // data_bn on the two load layouts of x: float4 of channel l16 & 3 at joints 4q..4q+3; dword of channel r at joint l16
+    const int cj = l16 & 3;
+    float sq[4] = {1.f, 1.f, 1.f, 1.f}, hq[4] = {0.f, 0.f, 0.f, 0.f}, sd[4] = {1.f, 1.f, 1.f, 1.f}, hd[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.in_scale) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (cj < Ci) { sq[e] = p.in_scale[(4 * q + e) * Ci + cj]; hq[e] = p.in_shift[(4 * q + e) * Ci + cj]; }
+            if (e < Ci) { sd[e] = p.in_scale[l16 * Ci + e]; hd[e] = p.in_shift[l16 * Ci + e]; }
+        }
+    }
+
+    f32x4 dAk[3], acc[COT], accr[COT], Sacc[COT], Bacc[COT];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) dAk[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ct = 0; ct < COT; ++ct) {
+        acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f}; accr[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+        Sacc[ct] = f32x4{0.f, 0.f, 0.f, 0.f}; Bacc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    const long long R = (long long)p.N * p.T;
+    const long long nw = (long long)gridDim.x * 8, gw = (long long)blockIdx.x * 8 + wave;
+    const long long r0 = R * gw / nw, r1 = R * (gw + 1) / nw;
+    const int nrows = (int)(r1 - r0);
+    const unsigned TS = (unsigned)p.T * 64u, TOS = (unsigned)p.To * 64u;
+    const unsigned lane_dyd = (unsigned)q * TS + l16 * 4u, lane_dyq = (unsigned)l16 * TS + q * 16u;
+    const unsigned lane_drd = (unsigned)q * TOS + l16 * 4u, lane_drq = (unsigned)l16 * TOS + q * 16u;
+    const unsigned lane_xq = (unsigned)(cj < Ci ? cj : 0) * TS + q * 16u, lane_xd = l16 * 4u;
+    int n = (int)(r0 / p.T), t = (int)(r0 - (long long)n * p.T);
+
+    struct Row { float dyd[S], drd[S], xd[4]; f32x4 dyq[COT], drq[COT], xq; };
+    auto load_row = [&](int nn, int tt, Row& rw) {
+        const unsigned so = (unsigned)tt * 64u;
+        const __amdgpu_buffer_rsrc_t rdy = make_rsrc(p.dy + (size_t)nn * CO * p.T * 16);
+        const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x + (size_t)nn * Ci * p.T * 16);
+#pragma unroll
+        for (int s = 0; s < S; ++s) rw.dyd[s] = bload(rdy, lane_dyd, so + (unsigned)s * 4u * TS);
+#pragma unroll
+        for (int ct = 0; ct < COT; ++ct) rw.dyq[ct] = bload4(rdy, lane_dyq, so + (unsigned)ct * 16u * TS);
+        rw.xq = bload4(rx, lane_xq, so);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rw.xd[r] = r < Ci ? bload(rx, lane_xd, so + (unsigned)r * TS) : 0.f;
+        if (has_res && (p.stride == 1 || (tt & 1) == 0)) {
+            const __amdgpu_buffer_rsrc_t rdr = make_rsrc(p.dres + (size_t)nn * CO * p.To * 16);
+            const unsigned sr = (unsigned)(p.stride == 1 ? tt : tt >> 1) * 64u;
+#pragma unroll
+            for (int s = 0; s < S; ++s) rw.drd[s] = bload(rdr, lane_drd, sr + (unsigned)s * 4u * TOS);
+#pragma unroll
+            for (int ct = 0; ct < COT; ++ct) rw.drq[ct] = bload4(rdr, lane_drq, sr + (unsigned)ct * 16u * TOS);
+        }
+    };
+    auto do_row = [&](int nn, int tt, bool have_next, Row& cur, Row& nxt) {
+        if (have_next) {
+            int n2 = nn, t2 = tt + 1;
+            if (t2 == p.T) { t2 = 0; ++n2; }
+            load_row(n2, t2, nxt);
+        }
+        const bool res_row = has_res && (p.stride == 1 || (tt & 1) == 0);
+        // x' = data_bn(x) in both layouts (channels past Ci stay 0)
+        float xq[4], xd[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            xq[e] = cj < Ci ? cur.xq[e] * sq[e] + hq[e] : 0.f;
+            xd[e] = e < Ci ? cur.xd[e] * sd[e] + hd[e] : 0.f;
+        }
+        // ---- data side
+        f32x4 dz = f32x4{0.f, 0.f, 0.f, 0.f}, dxa = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < S; ++s) dz = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[s], cur.dyd[s], dz, 0, 0, 0);
+        if (res_row) {
+#pragma unroll
+            for (int s = 0; s < S; ++s) dxa = __builtin_amdgcn_mfma_f32_16x16x4f32(wrreg[s], cur.drd[s], dxa, 0, 0, 0);
+        }
+        // ---- weight side (independent of dz: fills the pipe while the dz chain drains)
+        f32x4 z[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            z[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) z[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(akt[k][e], xq[e], z[k], 0, 0, 0);
+        }
+        const int kj = l16 >> 2;
+        f32x4 zs;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) zs[r] = kj == 0 ? z[0][r] : (kj == 1 ? z[1][r] : (kj == 2 ? z[2][r] : 0.f));
+#pragma unroll
+        for (int ct = 0; ct < COT; ++ct) {
+            Sacc[ct] += cur.dyq[ct];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.dyq[ct][r], zs[r], acc[ct], 0, 0, 0);
+        }
+        if (res_row) {
+#pragma unroll
+            for (int ct = 0; ct < COT; ++ct) {
+                Bacc[ct] += cur.drq[ct];
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    accr[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.drq[ct][r], xq[r], accr[ct], 0, 0, 0);
+            }
+        }
+        // ---- dA_k += x'^T dz_k (the lane's row group q is partition q)
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (r < Ci) dAk[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(xd[r], q == k ? dz[r] : 0.f, dAk[k], 0, 0, 0);
+        // ---- dx
+        if (p.dx) {
+            float dxr[4] = {0.f, 0.f, 0.f, 0.f};
+            __builtin_amdgcn_sched_barrier(0);
+            static_for<0, 16>([&](auto rt) {
+                constexpr int RR = decltype(rt)::value;
+                if ((rmask >> RR) & 1u) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (r < Ci) fma_ror<RR>(dxr[r], cfl[RR], dz[r], true);
+                }
+            });
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = dxr[r];
+                v += __shfl_xor(v, 16, 64);
+                v += __shfl_xor(v, 32, 64);
+                dxr[r] = v + dxa[r];                      // (row group 0 holds the residual product's rows ci)
+            }
+            if (q == 0) {
+                const __amdgpu_buffer_rsrc_t rs = make_rsrc(p.dx + (size_t)nn * Ci * p.T * 16);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (r < Ci) bstore(rs, lane_xd, (unsigned)tt * 64u + (unsigned)r * TS, dxr[r]);
+            }
+        }
+    };
+
+    Row ra, rb;
+    if (nrows > 0) load_row(n, t, ra);
+    for (int i = 0; i < nrows; i += 2) {
+        do_row(n, t, i + 1 < nrows, ra, rb);
+        if (++t == p.T) { t = 0; ++n; }
+        if (i + 1 < nrows) {
+            do_row(n, t, i + 2 < nrows, rb, ra);
+            if (++t == p.T) { t = 0; ++n; }
+        }
+    }
+
+    // partials: dA (dense 16 x 16 per k) and dW / S / dWr / dbr in the finalize's layout (Ci padded to 4); the 8 waves'
+    // rows are summed in order through LDS, one row per block leaves
+    __shared__ float red[8][768 + PART];
+    float* p1 = red[wave];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) p1[(k * 16 + 4 * q + i) * 16 + l16] = dAk[k][i];
+    float* part = p1 + 768;
+    const int kj = l16 >> 2, cij = l16 & 3;
+#pragma unroll
+    for (int ct = 0; ct < COT; ++ct) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int c = 16 * ct + 4 * q + r;
+            if (kj < 3) part[(kj * CO + c) * 4 + cij] = acc[ct][r];
+            if (l16 < 4) part[3 * CO * 4 + CO * 16 + c * 4 + l16] = accr[ct][r];
+        }
+        const int c = 16 * ct + l16;
+        float* ps = part + 3 * CO * 4 + c * 16 + 4 * q;
+        ps[0] = Sacc[ct][0]; ps[1] = Sacc[ct][1]; ps[2] = Sacc[ct][2]; ps[3] = Sacc[ct][3];
+        float b = (Bacc[ct][0] + Bacc[ct][1]) + (Bacc[ct][2] + Bacc[ct][3]);
+        b += __shfl_xor(b, 16, 64);
+        b += __shfl_xor(b, 32, 64);
+        if (q == 0) part[3 * CO * 4 + CO * 16 + CO * 4 + c] = b;
+    }
+    __syncthreads();
+    for (int e = tid; e < 768 + PART; e += 512) {
+        float sum = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < 8; ++wv) sum += red[wv][e];
+        if (e < 768) p.part1[(size_t)blockIdx.x * 768 + e] = sum;
+        else p.part2[(size_t)blockIdx.x * PART + (e - 768)] = sum;
+    }
+}
+
 // ---------------------------------------------------------------------- finalize
 struct FinParams {
     const float* part1; const float* part2; const float* A; const float* b;
@@ -1331,6 +1565,14 @@ bool gb_geom(int N, int Ci, int Co, int T, int nnz, GbGeom* g) {
 // second form: blocks for the data / weight kernels (two 256-thread blocks per CU, fewer for tiny inputs)
 bool gb16_shape(int Ci, int Co, const float* in_scale) {
     return !in_scale && (Ci == 32 || Ci == 64) && (Co == 32 || Co == 64) && !getenv("STEP_GCN_BWD_V1");
+}
+
+// first-block form (Ci <= 4): one fused kernel, a partial row per wave
+bool gbs_shape(int Ci, int Co) { return Ci >= 1 && Ci <= 4 && Co == 32 && !getenv("STEP_GCN_BWD_V1"); }
+int gbs_blocks(int N, int T) {
+    const long long rows = (long long)N * T;
+    const long long b = (rows + 15) / 16;
+    return (int)(b < 1 ? 1 : (b > 256 ? 256 : b));
 }
 
 // wide layers (Ci or Co > 64): channel groups per launch
@@ -1476,6 +1718,10 @@ extern "C" size_t step_gcn_bwd_ws_bytes(int N, int Ci, int Co, int K, int T) {
             return (((size_t)gw.nblk * gw.gi1 + 1) * 768 + ((size_t)gw.nblk + 1) * part2) * 4;
         }
     }
+    if (N >= 1 && T >= 1 && Ci >= 1 && Ci <= 4 && Co == 32) {                         // first-block form
+        const size_t rows = (size_t)gbs_blocks(N, T);
+        best = (rows + 1) * ((size_t)768 + 3 * (size_t)Co * 4 + (size_t)Co * 16 + (size_t)Co * 4 + Co) * 4;
+    }
     if ((Ci == 32 || Ci == 64) && (Co == 32 || Co == 64) && N >= 1 && T >= 1) {      // second form
         const size_t nb = (size_t)gb16_blocks(N, T);
         best = (nb + 1) * ((size_t)768 + 3 * (size_t)Co * Ci + (size_t)Co * 16 + (size_t)Co * Ci + Co) * 4;
@@ -1510,16 +1756,18 @@ extern "C" int step_gcn_bwd(const float* dy, const float* dres, const float* x, 
         STEP_REQUIRE(gb_geom(N, Ci, Co, T, a_nnz_max, &g), "step_gcn_bwd: unsupported N=%d Ci=%d Co=%d T=%d", N,
                      Ci, Co, T);
     }
-    const bool v2 = wide || gb16_shape(Ci, Co, in_scale);
+    const bool small = !wide && gbs_shape(Ci, Co);
+    const bool v2 = wide || small || gb16_shape(Ci, Co, in_scale);
     if (wide) {
         g.nblk1 = gw.nblk * gw.gi1;
         g.nblk2 = gw.nblk;
     }
+    if (small) g.nblk1 = g.nblk2 = gbs_blocks(N, T);
     if (v2) {
-        if (!wide) g.nblk1 = g.nblk2 = gb16_blocks(N, T);
-        g.copad = Co; g.cir = Ci;
+        if (!wide && !small) g.nblk1 = g.nblk2 = gb16_blocks(N, T);
+        g.copad = Co; g.cir = small ? 4 : Ci;
         g.part1 = 768;
-        g.part2 = 3 * (size_t)Co * Ci + (size_t)Co * 16 + (size_t)Co * Ci + Co;
+        g.part2 = 3 * (size_t)Co * g.cir + (size_t)Co * 16 + (size_t)Co * g.cir + Co;
     }
     const size_t need = ((size_t)(g.nblk1 + 1) * g.part1 + (size_t)(g.nblk2 + 1) * g.part2) * 4;
     if (ws_bytes < need) {
@@ -1548,7 +1796,13 @@ extern "C" int step_gcn_bwd(const float* dy, const float* dres, const float* x, 
     p.tiles_per_seq = (T + TT - 1) / TT;
     p.ntiles = N * p.tiles_per_seq;
     hipStream_t st = (hipStream_t)stream;
-    int rc = wide ? launch_gb16w(p, gw, st) : (v2 ? dispatch_gb16(p, g.nblk1, st) : dispatch_gb(p, g, st));
+    int rc;
+    if (small) {
+        hipLaunchKernelGGL((gcn_bwd_small_kernel<2>), dim3(g.nblk1), dim3(512), 0, st, p);
+        rc = step::check_launch("step_gcn_bwd(first block)");
+    } else {
+        rc = wide ? launch_gb16w(p, gw, st) : (v2 ? dispatch_gb16(p, g.nblk1, st) : dispatch_gb(p, g, st));
+    }
     if (rc) return rc;
     float* tot1 = p.part2 + (size_t)g.nblk2 * g.part2;   // (workspace rows: nblk1_ws + nblk2 + 2)
     float* tot2 = tot1 + g.part1;

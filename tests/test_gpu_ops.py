@@ -115,6 +115,7 @@ def test_tcn_transposed(Ci, Co, Kt, T):
     (3, 32, 20, 3, False, False), (32, 64, 17, 2, False, False), (64, 64, 9, 2, False, False),
     (7, 64, 12, 2, False, False), (64, 3, 11, 2, True, False), (32, 32, 8, 2, True, False),
     (32, 64, 10, 2, False, True), (64, 32, 24, 1, False, False),
+    (4, 32, 13, 5, True, True), (2, 32, 9, 300, False, False), (1, 32, 7, 2, False, False),   # first-block form
     # wide layers (north_star's C = 128 / 256 bench layers; classifier.py:42-49 leaves these blocks commented out)
     (64, 128, 9, 2, False, False), (128, 128, 7, 3, False, False), (128, 256, 6, 2, False, True),
     (256, 256, 5, 2, False, False), (256, 128, 4, 1, True, False),
