@@ -767,6 +767,182 @@ int launch_gcn16(const GcnParams& p, hipStream_t st) {
     return go(gcn_fwd16_kernel<2>);
 }
 
+// First block (Ci <= 4: the coordinate channels, data_bn folded into the load; Co = 32 | 64; residual 1x1 conv):
+// HBM-bound on the y / res_out writes.  Frame-per-wave, operands in registers, no barriers:
+//   z_k[ci][w] = SUM_v x'[ci,v] A_k[v,w]   16x16x4 with x' as the A operand, rows i -> channel i & 3, so every row
+//                                          group of the result holds all (<= 4) channels in its 4 registers
+//   y[c][w]    = SUM_(k,ci) W_k[c,ci] z_k[ci][w]   ONE contraction over k' = (k, ci): row group q supplies partition q
+//                                          (B = z_q, selected per lane), step e supplies channel e
+//   r[c][w]    = SUM_ci Wr[c,ci] x'[ci,w]  one MFMA per 16 output channels
+template <int COT>
+__global__ __launch_bounds__(512, COT == 2 ? 4 : 2) void gcn_fwd_small_kernel(GcnParams p) {
+    constexpr int CO = 16 * COT;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = lane >> 4, l16 = lane & 15;
+    const int Ci = p.Ci;
+    const bool has_res = p.res_w != nullptr;
+
+    float akb[3][4], wA[COT][4], wrA[COT], by[COT][4], br[COT][4];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) akb[k][e] = k < p.K ? p.A[(k * 16 + 4 * q + e) * 16 + l16] : 0.f;
+    float cs[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float s = 0.f;
+        if (k < p.K)
+            for (int v = 0; v < 16; ++v) s += p.A[(k * 16 + v) * 16 + l16];
+        cs[k] = s;
+    }
+#pragma unroll
+    for (int ct = 0; ct < COT; ++ct) {
+        const int c = 16 * ct + l16;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v = 0.f;
+            if (q < p.K && e < Ci)
+                v = p.w_transposed ? p.w[(size_t)e * (p.K * CO) + q * CO + c] : p.w[((size_t)q * CO + c) * Ci + e];
+            wA[ct][e] = v;
+        }
+        float vr = 0.f;
+        if (has_res && q < Ci) vr = p.res_transposed ? p.res_w[(size_t)q * CO + c] : p.res_w[(size_t)c * Ci + q];
+        wrA[ct] = vr;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int cc = 16 * ct + 4 * q + r;
+            float bsum = 0.f;
+            if (p.b)
+                for (int k = 0; k < p.K; ++k) bsum += p.b[k * CO + cc] * cs[k];
+            by[ct][r] = bsum;
+            br[ct][r] = (has_res && p.res_b) ? p.res_b[cc] : 0.f;
+        }
+    }
+    const int cj = l16 & 3;
+    float sq[4] = {1.f, 1.f, 1.f, 1.f}, hq[4] = {0.f, 0.f, 0.f, 0.f}, sd = 1.f, hd = 0.f;
+    if (p.in_scale) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (cj < Ci) { sq[e] = p.in_scale[(4 * q + e) * Ci + cj]; hq[e] = p.in_shift[(4 * q + e) * Ci + cj]; }
+        if (q < Ci) { sd = p.in_scale[l16 * Ci + q]; hd = p.in_shift[l16 * Ci + q]; }
+    }
+
+    // work unit: FR = 4 consecutive frames of one sequence.  The wave's results for them go through its own LDS
+    // stage [channel][frame][joint] and leave as 16-byte stores, 256 contiguous bytes per channel row (64-byte
+    // pieces scattered over 32 channel rows run the HBM write path at 2.4 TB/s: measured)
+    constexpr int FR = 4;
+    __shared__ __attribute__((aligned(16))) float stage_all[8][CO * FR * 16];
+    float* stg = stage_all[wave];
+    const int gps = (p.T + FR - 1) / FR;
+    const long long G = (long long)p.N * gps;
+    const long long nw = (long long)gridDim.x * 8, gw = (long long)blockIdx.x * 8 + wave;
+    const long long g0 = G * gw / nw, g1 = G * (gw + 1) / nw;
+    const int ngrp = (int)(g1 - g0);
+    const unsigned TS = (unsigned)p.T * 64u, TOS = (unsigned)p.To * 64u;
+    const unsigned lane_xq = (unsigned)(cj < Ci ? cj : 0) * TS + q * 16u;
+    const unsigned lane_xd = (unsigned)(q < Ci ? q : 0) * TS + l16 * 4u;
+    int n = (int)(g0 / gps), tg = (int)(g0 - (long long)n * gps);
+
+    struct Grp { f32x4 xq[FR]; float xd[FR]; };
+    auto load_grp = [&](int nn, int t0, Grp& gr) {
+        const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x + (size_t)nn * Ci * p.T * 16);
+#pragma unroll
+        for (int f = 0; f < FR; ++f) {
+            const int tt = t0 + f < p.T ? t0 + f : p.T - 1;
+            gr.xq[f] = bload4(rx, lane_xq, (unsigned)tt * 64u);
+            gr.xd[f] = bload(rx, lane_xd, (unsigned)tt * 64u);
+        }
+    };
+    // stage -> HBM: piece = 16 bytes of a (channel, frame) row; nf frames of the group are real
+    auto flush = [&](float* base, unsigned row_bytes, int f0, int nf) {
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(base);
+#pragma unroll
+        for (int it = 0; it < CO * FR * 4 / 64; ++it) {
+            const int idx = it * 64 + lane;
+            const int c = idx >> 4, piece = idx & 15;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(stg + c * (FR * 16) + piece * 4);
+            if ((piece >> 2) < nf)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs,
+                                                       (int)((unsigned)c * row_bytes + (unsigned)piece * 16u),
+                                                       (int)((unsigned)f0 * 64u), 0);
+        }
+    };
+    auto do_grp = [&](int nn, int t0, const Grp& cur) {
+        const int nf = p.T - t0 < FR ? p.T - t0 : FR;
+        float xds[FR];
+#pragma unroll
+        for (int f = 0; f < FR; ++f) {
+            float xq[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xq[e] = cj < Ci ? cur.xq[f][e] * sq[e] + hq[e] : 0.f;
+            xds[f] = q < Ci ? cur.xd[f] * sd + hd : 0.f;
+            f32x4 z[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                z[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    z[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(xq[e], akb[k][e], z[k], 0, 0, 0);
+            }
+            f32x4 zs;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) zs[e] = q == 0 ? z[0][e] : (q == 1 ? z[1][e] : (q == 2 ? z[2][e] : 0.f));
+#pragma unroll
+            for (int ct = 0; ct < COT; ++ct) {
+                f32x4 acc = {by[ct][0], by[ct][1], by[ct][2], by[ct][3]};
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (e < Ci) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wA[ct][e], zs[e], acc, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) stg[(16 * ct + 4 * q + r) * (FR * 16) + f * 16 + l16] = acc[r];
+            }
+        }
+        flush(p.y + (size_t)nn * CO * p.T * 16, TS, t0, nf);
+        if (has_res) {
+            // residual frames of the group: t0 is a multiple of 4, so they start at To index t0 / stride
+            const int st = p.stride;
+#pragma unroll
+            for (int f = 0; f < FR; f += 1) {
+                if (st == 2 && (f & 1)) continue;
+                const int fo = st == 2 ? f >> 1 : f;
+#pragma unroll
+                for (int ct = 0; ct < COT; ++ct) {
+                    f32x4 acc = {br[ct][0], br[ct][1], br[ct][2], br[ct][3]};
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wrA[ct], xds[f], acc, 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) stg[(16 * ct + 4 * q + r) * (FR * 16) + fo * 16 + l16] = acc[r];
+                }
+            }
+            flush(p.res_out + (size_t)nn * CO * p.To * 16, TOS, t0 / st, (nf + st - 1) / st);
+        }
+    };
+
+    Grp ga, gb;
+    if (ngrp > 0) load_grp(n, tg * FR, ga);
+    for (int i = 0; i < ngrp; i += 2) {
+        int n1 = n, tg1 = tg + 1;
+        if (tg1 == gps) { tg1 = 0; ++n1; }
+        if (i + 1 < ngrp) load_grp(n1, tg1 * FR, gb);
+        do_grp(n, tg * FR, ga);
+        n = n1; tg = tg1 + 1;
+        if (tg == gps) { tg = 0; ++n; }
+        if (i + 1 < ngrp) {
+            if (i + 2 < ngrp) load_grp(n, tg * FR, ga);
+            do_grp(n1, tg1 * FR, gb);
+        }
+    }
+}
+
+template <int COT>
+int launch_gcn_small(const GcnParams& p, hipStream_t st) {
+    const long long grps = (long long)p.N * ((p.T + 3) / 4);
+    long long b = (grps + 15) / 16;
+    b = b < 1 ? 1 : (b > 512 ? 512 : b);
+    hipLaunchKernelGGL((gcn_fwd_small_kernel<COT>), dim3((unsigned)b), dim3(512), 0, st, p);
+    return step::check_launch("step_gcn_fwd(first block)");
+}
+
 }  // namespace
 
 extern "C" int step_gcn_fwd(const float* x, const float* in_scale, const float* in_shift,
@@ -799,6 +975,8 @@ extern "C" int step_gcn_fwd(const float* x, const float* in_scale, const float* 
     p.ntiles = (int)nt;
     hipStream_t st = (hipStream_t)stream;
     if (wide) return launch_gcn16(p, st);
+    if (Ci <= 4 && (Co == 32 || Co == 64) && !getenv("STEP_GCN_FWD_V1"))
+        return Co == 32 ? launch_gcn_small<2>(p, st) : launch_gcn_small<4>(p, st);
     const int mt = p.Copad / 32;
     if (!in_scale && (Ci == 32 || Ci == 64) && !getenv("STEP_GCN_FWD_V1")) {
         const int rc = Ci == 32 ? dispatch_gcn2<32>(p, st) : dispatch_gcn2<64>(p, st);

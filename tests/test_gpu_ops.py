@@ -116,6 +116,7 @@ def test_tcn_transposed(Ci, Co, Kt, T):
     (7, 64, 12, 2, False, False), (64, 3, 11, 2, True, False), (32, 32, 8, 2, True, False),
     (32, 64, 10, 2, False, True), (64, 32, 24, 1, False, False),
     (4, 32, 13, 5, True, True), (2, 32, 9, 300, False, False), (1, 32, 7, 2, False, False),   # first-block form
+    (3, 64, 11, 2, False, False),
     # wide layers (north_star's C = 128 / 256 bench layers; classifier.py:42-49 leaves these blocks commented out)
     (64, 128, 9, 2, False, False), (128, 128, 7, 3, False, False), (128, 256, 6, 2, False, True),
     (256, 256, 5, 2, False, False), (256, 128, 4, 1, True, False),
@@ -252,3 +253,35 @@ def test_gcn_other_graph_strategies(strategy, Ci, Co, T):
     assert_close(gl[3].grad, leaves[3].grad, TOL, "db")
     supp = (A != 0).float()
     assert_close(gl[1].grad.cpu() * supp, leaves[1].grad * supp, TOL, "dA on supp(A)")
+
+
+@pytest.mark.parametrize("Ci,Co,T,N,stride,K", [(3, 32, 21, 37, 2, 3), (4, 32, 8, 3, 1, 2), (3, 64, 10, 5, 2, 3)])
+def test_first_block_forms_agree(Ci, Co, T, N, stride, K, monkeypatch):
+    """The fused first-block kernels (Ci <= 4) against the general tile kernels on a case no model here reaches:
+    data_bn scale/shift + residual conv at stride 2 (and K = 2), through the C-ABI."""
+    from step_amd import _lib
+    d = dev()
+    g = torch.Generator().manual_seed(11)
+    A = (A_spatial(True)[:K]).contiguous().to(d)
+    x = torch.randn(N, Ci, T, 16, generator=g).to(d)
+    isc, ish = (torch.rand(16 * Ci, generator=g) + 0.5).to(d), torch.randn(16 * Ci, generator=g).to(d)
+    w, b = (torch.randn(K * Co, Ci, generator=g) * 0.3).to(d), torch.randn(K * Co, generator=g).to(d)
+    rw, rb = (torch.randn(Co, Ci, generator=g) * 0.3).to(d), torch.randn(Co, generator=g).to(d)
+    To = (T - 1) // stride + 1
+    dy, dr = torch.randn(N, Co, T, 16, generator=g).to(d), torch.randn(N, Co, To, 16, generator=g).to(d)
+    nb = _lib.query("step_gcn_bwd_ws_bytes", N, Ci, Co, K, T)
+    ws = torch.empty(nb, dtype=torch.uint8, device=d)
+
+    def run():
+        y, r = torch.empty(N, Co, T, 16, device=d), torch.empty(N, Co, To, 16, device=d)
+        _lib.call("step_gcn_fwd", x, isc, ish, w, b, 0, A, 16, y, rw, rb, 0, r, N, Ci, Co, K, T, stride)
+        out = [torch.empty_like(t) for t in (x, w, b, A, rw, rb)]
+        _lib.call("step_gcn_bwd", dy, dr, x, isc, ish, w, b, 0, A, 16, rw, 0, *out, N, Ci, Co, K, T, stride, ws, nb)
+        return [y, r] + out
+
+    new = run()
+    monkeypatch.setenv("STEP_GCN_FWD_V1", "1")
+    monkeypatch.setenv("STEP_GCN_BWD_V1", "1")
+    old = run()
+    for name, a, o in zip(("y", "res_out", "dx", "dw", "db", "dA", "dres_w", "dres_b"), new, old):
+        assert_close(a, o.cpu(), 2e-5, name)
