@@ -173,6 +173,19 @@ int step_tcn_conv(const float* in, const float* in_scale, const float* in_shift,
                   int N, int Ci, int Co, int Tin, int Tout, int Kt, int stride, int pack_mode,
                   void* stream);
 
+/* Temporal conv of a frame-independent input: the decoder repeats its latent vector over T and V before the
+ * first st_gctn block (generator_cvae/net/CVAE_stgcn.py Decoder.forward, `z.repeat([1, 1, T, V])`), so that
+ * block's conv is one Co x Ci matrix per output frame (the taps inside the sequence there), stride 1:
+ *   wcum (T,Co,Ci) from w (Conv2d (Co,Ci,Kt) / ConvTranspose2d (Ci,Co,Kt) when transposed);
+ *   out[n,co,t,w] = epi( SUM_ci wcum[t][co][ci] * a0[n,ci,w] ), a0 (N,Ci,16) the activated graph-conv output of
+ *   ONE frame, epi as step_tcn_conv with res0 (N,Co,16) the residual of one frame.  Eval mode only.          */
+int step_tcn_const_weights(const float* w, float* wcum, int Co, int Ci, int Kt, int T, int transposed,
+                           void* stream);
+int step_tcn_const_fwd(const float* a0, const float* wcum, const float* bias,
+                       const float* out_scale, const float* out_shift,
+                       const float* res0, const float* res_scale, const float* res_shift, int out_relu,
+                       float* out, int N, int Ci, int Co, int T, void* stream);
+
 /* bf16-operand twins of the three entry points above (BASELINE config "classifier_stgcn_real_and_synth
  * training, bf16"; same reference statements: classifier.py:156-162 and its input gradient).
  * Tensors stay fp32 in HBM; activations (after `pre`) and weights are rounded to bf16 on their

@@ -111,9 +111,15 @@ class Decoder(nn.Module):
         N = z.size(0)
         zl = torch.cat((z, l), dim=1).float().contiguous()
         h = DenseFn.apply(zl, self.fcn.weight, self.fcn.bias, True)         # (N, 32)
-        h = h[:, :, None, None].expand(N, h.size(1), T, V).contiguous()     # z.repeat([1,1,T,V])
         _sync_nnz(self, self.decoder, "gctn")
-        for gcn, importance in zip(self.decoder, self.edge_importance):
+        blocks = list(zip(self.decoder, self.edge_importance))
+        if not self.training and not torch.is_grad_enabled() and V == 16:
+            # synthesis: z.repeat([1,1,T,V]) (:209) is never built - the first block works on the (N, 32) vectors
+            h, _ = blocks[0][0].forward_repeated(h, self.A * blocks[0][1], T)
+            blocks = blocks[1:]
+        else:
+            h = h[:, :, None, None].expand(N, h.size(1), T, V).contiguous()     # z.repeat([1,1,T,V])
+        for gcn, importance in blocks:
             h, _ = gcn(h, self.A * importance)
         h = DataBnFn.apply(self.data_bn, self.training, h, self.data_bn.weight, self.data_bn.bias)
         return h.unsqueeze(4)

@@ -5,7 +5,7 @@ children are parameter containers only; forward is one fused autograd Function
 """
 import torch.nn as nn
 
-from ..ops import BlockSpec, StGcnBlockFn
+from ..ops import BlockSpec, StGcnBlockFn, block_repeated_input_eval
 from .utils.tgcn import ConvTemporalGraphical, ConvTransposeTemporalGraphical
 
 
@@ -77,6 +77,23 @@ class _StBlock(nn.Module):
         if bnr is not None:
             params += [self.residual[0].weight, self.residual[0].bias, bnr.weight, bnr.bias]
         out = StGcnBlockFn.apply(spec, self.training, x, A, *params)
+        return out, A
+
+
+    def forward_repeated(self, h, A, T):
+        """Eval-mode forward of `x = h[:, :, None, None].repeat(1, 1, T, 16)` without building x
+        (the decoder's first block, CVAE_stgcn.py:209-212); no autograd graph is recorded."""
+        ci, co, kt, stride = self._geom
+        bnr = self.residual[1] if self._res_kind == "conv" else None
+        spec = BlockSpec(ci, co, kt, stride, self._res_kind, self.transposed, self.a_nnz_max,
+                         self.tcn[0], self.tcn[3], bnr, None)
+        g = self.graph_conv.conv
+        rw = rb = None
+        if bnr is not None:
+            rw, rb = self.residual[0].weight, self.residual[0].bias
+        out = block_repeated_input_eval(spec, h.detach(), A.detach(), T, g.weight.detach(), g.bias.detach(),
+                                        self.tcn[2].weight.detach(), self.tcn[2].bias.detach(),
+                                        None if rw is None else rw.detach(), None if rb is None else rb.detach())
         return out, A
 
 

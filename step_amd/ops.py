@@ -327,6 +327,48 @@ class StGcnBlockFn(torch.autograd.Function):
         return (None, None, dx if ctx.x_needs_grad else None, dA) + tuple(grads)
 
 
+def block_repeated_input_eval(spec, h, A_eff, T, gcn_w, gcn_b, tcn_w, tcn_b, res_w=None, res_b=None):
+    """Eval-mode st_gcn / st_gctn block whose input is ONE vector per sequence repeated over all T frames and 16
+    joints (CVAE_stgcn.py:209 `z.repeat([1, 1, T, V])` feeding decoder[0]) -> (N, Co, T, 16).
+
+    The repeated tensor is never built: graph conv, BN1 + ReLU (and a residual conv) run on a single frame, and
+    the temporal conv of that frame-independent activation is one Co x Co matrix per output frame (the taps that
+    fall inside the sequence there, step_tcn_const_weights / step_tcn_const_fwd) with BN2, the residual and the
+    final ReLU in its epilogue."""
+    s = spec
+    h = _f32(h)
+    A_eff = _f32(A_eff)
+    N, Ci = h.shape
+    if Ci != s.Ci or s.stride != 1 or s.data_bn is not None:
+        raise _lib.StepHipError("repeated-input block: needs (N,%d) input, stride 1, no data_bn" % s.Ci)
+    Co, Kt, K = s.Co, s.Kt, A_eff.shape[0]
+    dev = h.device
+    x1 = h[:, :, None, None].expand(N, Ci, 1, 16).contiguous()            # one frame
+    y0 = torch.empty((N, Co, 1, 16), dtype=torch.float32, device=dev)
+    r0 = torch.empty((N, Co, 1, 16), dtype=torch.float32, device=dev) if s.residual == "conv" else None
+    gcn_w, gcn_b, tcn_w, tcn_b = _f32(gcn_w), _f32(gcn_b), _f32(tcn_w), _f32(tcn_b)
+    if s.residual == "conv":
+        res_w, res_b = _f32(res_w), _f32(res_b)
+    else:
+        res_w = res_b = None
+    _lib.call("step_gcn_fwd", x1, None, None, gcn_w, gcn_b, int(s.transposed), A_eff, s.nnz, y0,
+              res_w, res_b, int(s.transposed), r0, N, Ci, Co, K, 1, 1)
+    _, _, s1, h1 = bn_prepare(None, 0, s.bn1, False)
+    a0 = affine_act(y0, s1, h1, None, None, None, True, 0)
+    wcum = torch.empty((T, Co, Co), dtype=torch.float32, device=dev)
+    _lib.call("step_tcn_const_weights", tcn_w, wcum, Co, Co, Kt, T, int(s.transposed))
+    _, _, s2, h2 = bn_prepare(None, 0, s.bn2, False)
+    res0 = sr = hr = None
+    if s.residual == "conv":
+        _, _, sr, hr = bn_prepare(None, 0, s.bnr, False)
+        res0 = r0
+    elif s.residual == "identity":
+        res0 = x1
+    out = torch.empty((N, Co, T, 16), dtype=torch.float32, device=dev)
+    _lib.call("step_tcn_const_fwd", a0, wcum, tcn_b, s2, h2, res0, sr, hr, 1, out, N, Co, Co, T)
+    return out
+
+
 # ---------------------------------------------------------------------------- heads
 class PoolFn(torch.autograd.Function):
     """F.avg_pool2d(x, x.size()[2:]) (+ mean over M == 1), classifier.py:81-82 -> (N, C)"""

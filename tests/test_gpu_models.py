@@ -188,6 +188,12 @@ def test_cvae_ckpt105_eval_and_train():
         assert_close(lsig, d["lsig"], 1e-4, "lsig")
         assert_close(m.decoder(d["z"], d["onehot"], 75, 16), d["dec75"], 1e-4, "dec75")
         assert_close(m.decoder(d["z"][:2], d["onehot"][:2], 240, 16), d["dec240"], 1e-4, "dec240")
+        # those two ran the synthesis path that never builds z.repeat([1,1,T,V]); the general path (taken whenever
+        # autograd records) builds it and must give the same frames
+        fast = m.decoder(d["z"], d["onehot"], 75, 16)
+    slow = m.decoder(d["z"], d["onehot"], 75, 16)
+    assert slow.requires_grad and not fast.requires_grad
+    assert_close(fast, slow.detach(), 1e-5, "decoder: repeated-input path vs materialised repeat")
     # training-mode forward/backward (encoder -> reparam with the fixture's eps -> decoder)
     m.train()
     d = sub(load_npz("cvae_train"), "", device=D)

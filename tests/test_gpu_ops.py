@@ -285,3 +285,38 @@ def test_first_block_forms_agree(Ci, Co, T, N, stride, K, monkeypatch):
     old = run()
     for name, a, o in zip(("y", "res_out", "dx", "dw", "db", "dA", "dres_w", "dres_b"), new, old):
         assert_close(a, o.cpu(), 2e-5, name)
+
+
+@pytest.mark.parametrize("C,Kt,T,transposed,res", [(32, 75, 75, True, "identity"), (64, 75, 11, True, "conv"),
+                                                    (32, 9, 40, False, None), (64, 75, 240, False, "identity")])
+def test_tcn_const_input(C, Kt, T, transposed, res):
+    """step_tcn_const_weights / step_tcn_const_fwd against the convolution of the materialised repeat
+    (CVAE_stgcn.py:209 followed by tcn[2] of decoder[0], :359-365), eval epilogue included"""
+    from step_amd import _lib
+    d = dev()
+    g = torch.Generator().manual_seed(12)
+    N = 5
+    a0 = torch.relu(torch.randn(N, C, 16, generator=g))
+    w = torch.randn(C, C, Kt, 1, generator=g) * 0.05
+    b = torch.randn(C, generator=g)
+    s2, h2 = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    a = a0[:, :, None, :].expand(N, C, T, 16)
+    pad = ((Kt - 1) // 2, 0)
+    u = F.conv_transpose2d(a, w, b, padding=pad) if transposed else F.conv2d(a, w, b, padding=pad)
+    ref = u * s2.view(1, C, 1, 1) + h2.view(1, C, 1, 1)
+    r0 = sr = hr = None
+    if res is not None:
+        r0 = torch.randn(N, C, 16, generator=g)
+        rr = r0[:, :, None, :]
+        if res == "conv":
+            sr, hr = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+            rr = rr * sr.view(1, C, 1, 1) + hr.view(1, C, 1, 1)
+        ref = ref + rr
+    ref = torch.relu(ref)
+    wcum = torch.empty(T, C, C, device=d)
+    _lib.call("step_tcn_const_weights", w.to(d), wcum, C, C, Kt, T, int(transposed))
+    out = torch.empty(N, C, T, 16, device=d)
+    dv = lambda t: None if t is None else t.to(d)
+    _lib.call("step_tcn_const_fwd", a0.to(d), wcum, b.to(d), s2.to(d), h2.to(d), dv(r0), dv(sr), dv(hr), 1, out,
+              N, C, C, T)
+    assert_close(out, ref, TOL, "const-input tcn")
