@@ -1372,11 +1372,12 @@ __global__ __launch_bounds__(512, 2) void gcn_bwd_small_kernel(GbParams p) {
                 if ((rmask >> RR) & 1u) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        if (r < Ci) fma_ror<RR>(dxr[r], cfl[RR], dz[r], true);
+                        if (r < Ci) fma_ror<RR>(dxr[r], cfl[RR], dz[r], r == 0);
                 }
             });
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
+                if (r >= Ci) continue;
                 float v = dxr[r];
                 v += __shfl_xor(v, 16, 64);
                 v += __shfl_xor(v, 32, 64);
@@ -1516,21 +1517,34 @@ __global__ void gcn_bwd_finalize_kernel(FinParams f) {
     }
 }
 
-// dst[c] = SUM_r src[r][c], rows in order (reproducible); 4 independent chains per thread
-__global__ void sum_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int nrows,
-                                int ncols) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= ncols) return;
+// dst[c] = SUM_r src[r][c] for the two partial arrays of a launch, in a fixed order (reproducible): a block is
+// 64 columns x 4 row quarters, 4 independent chains per thread, the quarters combined through LDS
+__global__ __launch_bounds__(256) void sum_rows_kernel(const float* __restrict__ src1, float* __restrict__ dst1,
+                                                       int nrows1, int ncols1, const float* __restrict__ src2,
+                                                       float* __restrict__ dst2, int nrows2, int ncols2) {
+    __shared__ float red[4][64];
+    const int nb1 = (ncols1 + 63) / 64;
+    const bool first = (int)blockIdx.x < nb1;
+    const float* src = first ? src1 : src2;
+    float* dst = first ? dst1 : dst2;
+    const int nrows = first ? nrows1 : nrows2, ncols = first ? ncols1 : ncols2;
+    const int c = ((int)blockIdx.x - (first ? 0 : nb1)) * 64 + (threadIdx.x & 63);
+    const int g = threadIdx.x >> 6;
+    const int ra = (int)((long long)nrows * g / 4), rb = (int)((long long)nrows * (g + 1) / 4);
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int r = 0;
-    for (; r + 3 < nrows; r += 4) {
-        s0 += src[(size_t)r * ncols + c];
-        s1 += src[(size_t)(r + 1) * ncols + c];
-        s2 += src[(size_t)(r + 2) * ncols + c];
-        s3 += src[(size_t)(r + 3) * ncols + c];
+    if (c < ncols) {
+        int r = ra;
+        for (; r + 3 < rb; r += 4) {
+            s0 += src[(size_t)r * ncols + c];
+            s1 += src[(size_t)(r + 1) * ncols + c];
+            s2 += src[(size_t)(r + 2) * ncols + c];
+            s3 += src[(size_t)(r + 3) * ncols + c];
+        }
+        for (; r < rb; ++r) s0 += src[(size_t)r * ncols + c];
     }
-    for (; r < nrows; ++r) s0 += src[(size_t)r * ncols + c];
-    dst[c] = (s0 + s1) + (s2 + s3);
+    red[g][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (g == 0 && c < ncols) dst[c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
 struct GbGeom {
@@ -1806,10 +1820,8 @@ extern "C" int step_gcn_bwd(const float* dy, const float* dres, const float* x, 
     if (rc) return rc;
     float* tot1 = p.part2 + (size_t)g.nblk2 * g.part2;   // (workspace rows: nblk1_ws + nblk2 + 2)
     float* tot2 = tot1 + g.part1;
-    hipLaunchKernelGGL(sum_rows_kernel, dim3(step::ceil_div((int)g.part1, 128)), dim3(128), 0, st, p.part1,
-                       tot1, g.nblk1, (int)g.part1);
-    hipLaunchKernelGGL(sum_rows_kernel, dim3(step::ceil_div((int)g.part2, 128)), dim3(128), 0, st, p.part2,
-                       tot2, g.nblk2, (int)g.part2);
+    hipLaunchKernelGGL(sum_rows_kernel, dim3(step::ceil_div((int)g.part1, 64) + step::ceil_div((int)g.part2, 64)),
+                       dim3(256), 0, st, p.part1, tot1, g.nblk1, (int)g.part1, p.part2, tot2, g.nblk2, (int)g.part2);
     FinParams f{};
     f.part1 = tot1; f.part2 = tot2; f.A = A_eff; f.b = b;
     f.dw = dw; f.db = db; f.dA = dA; f.dres_w = dres_w; f.dres_b = dres_b;
