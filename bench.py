@@ -271,6 +271,9 @@ def main():
                     help="MFMA operand type of the temporal convs for the headline number (f32 = BASELINE "
                          "configs[1]); with f32 a short bf16-operand run is reported beside it")
     ap.add_argument("--no-bf16", action="store_true", help="skip the secondary bf16-operand run")
+    ap.add_argument("--sync-bn", action="store_true",
+                    help="BatchNorm statistics over all ranks (the reference's single-device batch), "
+                         "step_amd.parallel.sync_batchnorm; default is per-rank statistics (DDP semantics)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -291,6 +294,7 @@ def main():
     import step_amd
     model = step_amd.set_mfma_dtype(make_model(device).train(), args.mfma)
     parallel.broadcast_parameters(model)
+    parallel.sync_batchnorm(args.sync_bn and world > 1)
     opt = torch.optim.Adam(model.parameters(), lr=0.1, weight_decay=1e-4)
     bucket = parallel.GradBucket(model.parameters())
     x, y = synth(args.batch, args.frames, 1234 + rank, device)
@@ -385,7 +389,7 @@ def main():
                                    % (args.batch, args.frames,
                                       ", bf16 MFMA operands in the temporal convs" if args.mfma == "bf16" else ""),
                        "global_batch": args.batch * world, "frames": args.frames,
-                       "parallelism": "dp%d" % world},
+                       "parallelism": "dp%d%s" % (world, "+syncbn" if args.sync_bn and world > 1 else "")},
             "inference_sequences_per_s_per_gpu": round(infer, 1),
             "step_tflops_per_gpu": round(3.0 * model_flops_per_sequence(args.frames) * args.batch * args.steps / dt / 1e12, 2),
             "rehearsal": ("%d ranks share one GPU, collectives over gloo through host memory: not a scaling number"

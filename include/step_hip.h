@@ -59,6 +59,19 @@ int step_bn_train_prepare(const float* x, int N, int C, int T, int V, int bn_mod
                           float* mean, float* invstd, float* scale, float* shift,
                           void* ws, size_t ws_bytes, void* stream);
 
+/* The two halves of step_bn_train_prepare, for batch statistics taken over SEVERAL GPUs (synchronised BatchNorm:
+ * with per-rank statistics an 8 x 512 data-parallel step is not the reference's single-device batch-4096
+ * BatchNorm, nn.BatchNorm2d in classifier.py:154-164).  _stats leaves SUM x, SUM x^2 per group in `sums`
+ * (2*G doubles, caller-owned: the host all-reduces them and the element counts across ranks); _finalize takes
+ * the combined sums and the combined count and does what step_bn_train_prepare does after its own reduction;
+ * count == 0: the count is read from sums[2*G] on the device (a host that all-reduced [sums, count] in one
+ * buffer needs no device-to-host copy).                                                                    */
+int step_bn_train_stats(const float* x, int N, int C, int T, int V, int bn_mode, double* sums,
+                        void* ws, size_t ws_bytes, void* stream);
+int step_bn_train_finalize(const double* sums, double count, const float* gamma, const float* beta,
+                           float* running_mean, float* running_var, float momentum, float eps,
+                           float* mean, float* invstd, float* scale, float* shift, int G, void* stream);
+
 /* step_bn_train_prepare for callers that cannot allocate (code under HIP graph capture, tight serving loops,
  * harnesses that forbid hipMalloc).  It has NO counterpart in the reference.  Same arguments, results and
  * launches as step_bn_train_prepare (bit-identical outputs) minus the workspace: the chunk partials, totals

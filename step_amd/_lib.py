@@ -24,6 +24,8 @@ SIGNATURES = {
     "step_bn_eval_prepare": (I, [P, P, P, P, F, P, P, I, P]),
     "step_bn_ws_bytes": (Z, [I]),
     "step_bn_train_prepare": (I, [P, I, I, I, I, I, P, P, P, P, F, F, P, P, P, P, P, Z, P]),
+    "step_bn_train_stats": (I, [P, I, I, I, I, I, P, P, Z, P]),
+    "step_bn_train_finalize": (I, [P, DBL, P, P, P, P, F, F, P, P, P, P, I, P]),
     "step_bn_train_prepare_static": (I, [P, I, I, I, I, I, P, P, P, P, F, F, P, P, P, P, P]),
     "step_affine_act": (I, [P, P, P, P, P, P, I, P, I, I, I, I, I, P]),
     "step_bn_bwd_reduce": (I, [P, P, P, P, P, I, I, I, I, I, I, P, P, Z, P]),

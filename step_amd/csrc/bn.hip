@@ -146,6 +146,7 @@ __global__ void bn_train_finalize_kernel(const double* __restrict__ tot, const f
                                          int G, double count) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= G) return;
+    if (count <= 0.0) count = tot[2 * G];        // combined element count behind the sums (synchronised BatchNorm)
     const double m = tot[2 * g] / count;
     double var = tot[2 * g + 1] / count - m * m;
     var = var > 0.0 ? var : 0.0;
@@ -383,6 +384,39 @@ extern "C" int step_bn_eval_prepare(const float* gamma, const float* beta, const
                  N, C, T, V);                                                                 \
     STEP_REQUIRE(bn_mode == 0 || bn_mode == 1, name ": bn_mode must be 0 or 1")
 
+extern "C" int step_bn_train_stats(const float* x, int N, int C, int T, int V, int bn_mode, double* sums,
+                                   void* ws, size_t wsb, void* stream) {
+    BN_SHAPE_CHECK("step_bn_train_stats");
+    STEP_REQUIRE(x && sums && ws, "step_bn_train_stats: null pointer");
+    const int G = bn_mode ? 16 * C : C;
+    if (wsb < ws_bytes(G)) {
+        step::set_error("step_bn_train_stats: workspace %zu < %zu bytes", wsb, ws_bytes(G));
+        return STEP_ERR_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int nch = chunks_for(N);
+    double* part = (double*)ws;
+    hipLaunchKernelGGL((bn_reduce_kernel<false, 0>), dim3(C, nch), dim3(BN_THREADS), 0, st, x, nullptr,
+                       nullptr, nullptr, nullptr, part, N, C, T, V, bn_mode, nch);
+    hipLaunchKernelGGL(bn_sum_chunks_kernel, dim3(step::ceil_div(2 * G, 128)), dim3(128), 0, st, part,
+                       sums, G, nch);
+    return step::check_launch("step_bn_train_stats");
+}
+
+extern "C" int step_bn_train_finalize(const double* sums, double count, const float* gamma, const float* beta,
+                                      float* running_mean, float* running_var, float momentum, float eps,
+                                      float* mean, float* invstd, float* scale, float* shift, int G,
+                                      void* stream) {
+    STEP_REQUIRE(sums && mean && invstd && scale && shift && G > 0 && (count >= 1.0 || count == 0.0),
+                 "step_bn_train_finalize: bad args (G=%d count=%g)", G, count);
+    STEP_REQUIRE((running_mean == nullptr) == (running_var == nullptr),
+                 "step_bn_train_finalize: running stats come in pairs");
+    hipLaunchKernelGGL(bn_train_finalize_kernel, dim3(step::ceil_div(G, 128)), dim3(128), 0, (hipStream_t)stream,
+                       sums, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift, G,
+                       count);
+    return step::check_launch("step_bn_train_finalize");
+}
+
 extern "C" int step_bn_train_prepare(const float* x, int N, int C, int T, int V, int bn_mode,
                                      const float* gamma, const float* beta, float* running_mean,
                                      float* running_var, float momentum, float eps, float* mean,
@@ -390,26 +424,17 @@ extern "C" int step_bn_train_prepare(const float* x, int N, int C, int T, int V,
                                      size_t wsb, void* stream) {
     BN_SHAPE_CHECK("step_bn_train_prepare");
     STEP_REQUIRE(x && mean && invstd && scale && shift && ws, "step_bn_train_prepare: null pointer");
-    STEP_REQUIRE((running_mean == nullptr) == (running_var == nullptr),
-                 "step_bn_train_prepare: running stats come in pairs");
     const int G = bn_mode ? 16 * C : C;
     if (wsb < ws_bytes(G)) {
         step::set_error("step_bn_train_prepare: workspace %zu < %zu bytes", wsb, ws_bytes(G));
         return STEP_ERR_WORKSPACE;
     }
-    hipStream_t st = (hipStream_t)stream;
-    const int nch = chunks_for(N);
-    double* part = (double*)ws;
-    double* tot = part + (size_t)BN_MAX_CHUNKS * G * 2;
-    hipLaunchKernelGGL((bn_reduce_kernel<false, 0>), dim3(C, nch), dim3(BN_THREADS), 0, st, x, nullptr,
-                       nullptr, nullptr, nullptr, part, N, C, T, V, bn_mode, nch);
-    hipLaunchKernelGGL(bn_sum_chunks_kernel, dim3(step::ceil_div(2 * G, 128)), dim3(128), 0, st, part,
-                       tot, G, nch);
+    double* tot = (double*)ws + (size_t)BN_MAX_CHUNKS * G * 2;
+    const int rc = step_bn_train_stats(x, N, C, T, V, bn_mode, tot, ws, wsb, stream);
+    if (rc != STEP_OK) return rc;
     const double count = bn_mode ? (double)N * T : (double)N * T * 16;
-    hipLaunchKernelGGL(bn_train_finalize_kernel, dim3(step::ceil_div(G, 128)), dim3(128), 0, st, tot,
-                       gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale,
-                       shift, G, count);
-    return step::check_launch("step_bn_train_prepare");
+    return step_bn_train_finalize(tot, count, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd,
+                                  scale, shift, G, stream);
 }
 
 // ---- the entry point that allocates nothing (no counterpart in the reference) ----------------------------

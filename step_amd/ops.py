@@ -29,6 +29,27 @@ def a_nnz_max(A):
 
 
 # ------------------------------------------------------------------------ BatchNorm
+_SYNC_BN = {"on": False, "group": None}
+
+
+def set_sync_bn(enabled, group=None):
+    """Train-mode BatchNorm statistics over all ranks of `group` (step_amd.parallel.sync_batchnorm)."""
+    _SYNC_BN["on"], _SYNC_BN["group"] = bool(enabled), group
+
+
+def _sync_world():
+    import torch.distributed as dist
+    if not _SYNC_BN["on"] or not dist.is_available() or not dist.is_initialized():
+        return 1
+    return dist.get_world_size(_SYNC_BN["group"])
+
+
+def _sync_sums(sums):
+    """all-reduce [sums..., element count] (fp64) over the ranks; nothing comes back to the host"""
+    from . import parallel
+    parallel._all_reduce_sum(sums, _SYNC_BN["group"])
+
+
 def bn_eval_prepare(weight, bias, running_mean, running_var):
     G = running_mean.numel()
     scale = torch.empty(G, dtype=torch.float32, device=running_mean.device)
@@ -45,6 +66,16 @@ def bn_train_prepare(x, bn_mode, weight, bias, running_mean, running_var, moment
     invstd, scale, shift = torch.empty_like(mean), torch.empty_like(mean), torch.empty_like(mean)
     nb = _lib.query("step_bn_ws_bytes", G)
     ws = _ws(nb, dev)
+    if _sync_world() > 1:
+        # synchronised BatchNorm: local SUM x, SUM x^2 and the local element count travel in one fp64 buffer;
+        # the finalize kernel reads the combined count from its last slot (count argument 0)
+        sums = torch.empty(2 * G + 1, dtype=torch.float64, device=dev)
+        _lib.call("step_bn_train_stats", x, N, C, T, V, bn_mode, sums, ws, nb)
+        sums[2 * G] = float(N * T if bn_mode else N * T * V)
+        _sync_sums(sums)
+        _lib.call("step_bn_train_finalize", sums, 0.0, weight, bias, running_mean, running_var, momentum, BN_EPS,
+                  mean, invstd, scale, shift, G)
+        return mean, invstd, scale, shift
     _lib.call("step_bn_train_prepare", x, N, C, T, V, bn_mode, weight, bias, running_mean, running_var,
               momentum, BN_EPS, mean, invstd, scale, shift, ws, nb)
     return mean, invstd, scale, shift
@@ -76,7 +107,7 @@ def bn_backward(dy, x, mask_src, scale, shift, mask_mode, mean, invstd, gamma, t
     dev = x.device
     nb = _lib.query("step_bn_ws_bytes", G)
     ws = _ws(nb, dev)
-    sums = torch.empty(2 * G, dtype=torch.float64, device=dev)
+    sums = torch.empty(2 * G + 1, dtype=torch.float64, device=dev)
     _lib.call("step_bn_bwd_reduce", dy, x, mask_src, scale, shift, mask_mode, N, C, T, V, bn_mode, sums, ws, nb)
     dgamma = torch.empty(G, dtype=torch.float32, device=dev)
     dbeta = torch.empty_like(dgamma)
@@ -87,6 +118,20 @@ def bn_backward(dy, x, mask_src, scale, shift, mask_mode, mean, invstd, gamma, t
             dx, accumulate = dx_accum, 1
         else:
             dx = torch.empty_like(x)
+    if training and _sync_world() > 1:
+        # synchronised BatchNorm: dgamma / dbeta come from this rank's sums (the gradient all-reduce averages them
+        # like every other parameter gradient); dx needs SUM g and SUM g*x over ALL ranks.  The apply kernel divides
+        # by the local element count, so the combined sums are scaled by local / combined count on the device.
+        _lib.call("step_bn_bwd_apply", dy, x, mask_src, scale, shift, mask_mode, mean, invstd, gamma, sums,
+                  1, 0, None, dgamma, dbeta, N, C, T, V, bn_mode, ws, nb)
+        if dx is not None:
+            local = float(N * T if bn_mode else N * T * V)
+            sums[2 * G] = local
+            _sync_sums(sums)
+            sums[:2 * G] *= local / sums[2 * G]
+            _lib.call("step_bn_bwd_apply", dy, x, mask_src, scale, shift, mask_mode, mean, invstd, gamma, sums,
+                      1, accumulate, dx, None, None, N, C, T, V, bn_mode, ws, nb)
+        return dx, dgamma, dbeta
     _lib.call("step_bn_bwd_apply", dy, x, mask_src, scale, shift, mask_mode, mean, invstd, gamma, sums,
               int(training), accumulate, dx, dgamma, dbeta, N, C, T, V, bn_mode, ws, nb)
     return dx, dgamma, dbeta
@@ -281,8 +326,12 @@ class StGcnBlockFn(torch.autograd.Function):
 
         # tail: out = relu(bn2(u) + res)
         dr = dgr = dbr = None
-        if s.residual == "conv":
+        if s.residual == "conv" and not (training and _sync_world() > 1):
             du, dg2, db2, dr, dgr, dbr = bn_backward_tail_pair(dout, out, u, r, m2, i2, bn2_w, mr, ir, bnr_w, training)
+        elif s.residual == "conv":
+            # synchronised BatchNorm: the fused pair cannot stop between its reduce and its apply for the all-reduce
+            du, dg2, db2 = bn_backward(dout, u, out, None, None, 1, m2, i2, bn2_w, training, 0)
+            dr, dgr, dbr = bn_backward(dout, r, out, None, None, 1, mr, ir, bnr_w, training, 0)
         else:
             du, dg2, db2 = bn_backward(dout, u, out, None, None, 1, m2, i2, bn2_w, training, 0)
 
@@ -468,6 +517,8 @@ class BnRowsFn(torch.autograd.Function):
         y = torch.empty_like(x)
         mean = torch.empty(G, dtype=torch.float32, device=x.device)
         invstd = torch.empty_like(mean)
+        if training and _sync_world() > 1:
+            raise _lib.StepHipError("synchronised BatchNorm does not cover the hybrid head's BatchNorm1d on (N, G) rows")
         _lib.call("step_bn_rows_fwd", x, weight, bias, bn.running_mean, bn.running_var, int(training),
                   BN_MOMENTUM, BN_EPS, y, mean, invstd, N, G)
         if training:

@@ -4,7 +4,9 @@ The ST-GCN stack shards over the batch (sequences are independent); t
 exchange step of a training iteration is ONE all-reduce of the flat gradient bucket
 (716 292 fp32 = 2.87 MB for the classifiers) between backward and optimizer.step().
 Inference and synthesis use no collective at all.  BatchNorm statistics stay local to a
-rank (standard DDP semantics); the reference itself is single-device.
+rank by default (standard DDP semantics); the reference itself is single-device, and
+``sync_batchnorm(True)`` reproduces ITS statistics (one batch over all ranks) at the price of one small fp64
+all-reduce per BatchNorm in forward and one in backward.
 """
 import os
 
@@ -121,3 +123,13 @@ def broadcast_parameters(module, src=0, group=None):
             n = t.numel()
             t.copy_(flat[off:off + n].view_as(t))
             off += n
+
+
+def sync_batchnorm(enabled=True, group=None):
+    """Train-mode BatchNorm of every st_gcn / st_gctn block and of `data_bn` over the batch of ALL ranks: with it
+    W ranks x N/W sequences compute what the reference's single device computes on N (same normalisation, running
+    statistics and gradients).  Per BatchNorm the ranks all-reduce 2*G + 1 doubles (SUM x, SUM x^2, element count)
+    in forward and (SUM g, SUM g*x, count) in backward; dgamma / dbeta stay local and are averaged with the other
+    gradients by GradBucket.all_reduce_mean.  The hybrid head's BatchNorm1d on feature rows is not covered."""
+    from . import ops
+    ops.set_sync_bn(enabled, group)

@@ -32,6 +32,7 @@ with torch.no_grad():
         p.add_(0.01 * rank)                 # ranks start different ...
 m = m.to(dev).train()
 parallel.broadcast_parameters(m)            # ... and are made equal to rank 0
+parallel.sync_batchnorm(os.environ.get("STEP_TEST_SYNCBN") == "1")
 g = torch.Generator().manual_seed(5)
 X = torch.randn(12, 3, 75, 16, 1, generator=g) * 0.5
 Y = torch.randint(0, 4, (12,), generator=g)
@@ -44,7 +45,8 @@ assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(bucket.params, buck
 bucket.all_reduce_mean()
 torch.cuda.synchronize()
 torch.save({"flat": bucket.flat.cpu(), "w0": next(m.parameters()).detach().cpu(),
-            "rm": m.st_gcn_networks[0].tcn[0].running_mean.cpu()}, '__OUT__/rank%d.pt' % rank)
+            "rm": m.st_gcn_networks[0].tcn[0].running_mean.cpu(), "rv": m.st_gcn_networks[2].tcn[3].running_var.cpu(),
+            "dbn_rm": m.data_bn.running_mean.cpu(), "out": out.detach().cpu()}, '__OUT__/rank%d.pt' % rank)
 dist.barrier(); dist.destroy_process_group()
 sys.stdout.write("rank%d-ok\n" % rank); sys.stdout.flush()
 """
@@ -85,6 +87,51 @@ def test_two_rank_gradients_equal_mean_of_shard_gradients(tmp_path):
     assert torch.equal(r0["flat"], want), float((r0["flat"] - want).abs().max())
     assert torch.equal(r0["rm"], rms[0]) and torch.equal(r1["rm"], rms[1])    # BN statistics stay per rank
     assert torch.equal(r0["w0"], next(m.parameters()).detach().cpu())
+
+
+def test_two_ranks_with_synchronised_batchnorm_equal_one_device(tmp_path):
+    """parallel.sync_batchnorm: 2 ranks x 6 sequences give what ONE device gives on the 12 (the reference's
+    single-device BatchNorm, classifier.py:154-164): outputs, running statistics and the averaged gradients"""
+    from step_amd.net.classifier import Classifier
+    from tests.util import assert_close
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER.replace("__ROOT__", ROOT).replace("__OUT__", str(tmp_path)))
+    env = dict(os.environ, STEP_DIST_BACKEND="gloo", STEP_LOCAL_DEVICE="0", OMP_NUM_THREADS="2",
+               HSA_ENABLE_IPC_MODE_LEGACY="0", STEP_TEST_SYNCBN="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29533", str(script)],
+                         env=env, capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    r0 = torch.load(tmp_path / "rank0.pt", weights_only=True)
+    r1 = torch.load(tmp_path / "rank1.pt", weights_only=True)
+    assert torch.equal(r0["flat"], r1["flat"])
+    for k in ("rm", "rv", "dbn_rm"):
+        assert torch.equal(r0[k], r1[k]), k                       # both ranks track the same statistics
+
+    D = "cuda:0"
+    g = torch.Generator().manual_seed(5)
+    X = torch.randn(12, 3, 75, 16, 1, generator=g) * 0.5
+    Y = torch.randint(0, 4, (12,), generator=g)
+    m = Classifier(3, 4, {"strategy": "spatial"})
+    m.load_state_dict(ckpt("ckpt_classifier_real_only_epoch395"))
+    m = m.to(D).train()
+    o, _ = m(X.to(D))
+    F.cross_entropy(o, Y.to(D)).backward()
+    want = torch.cat([p.grad.reshape(-1) for p in m.parameters()]).cpu()
+    assert_close(torch.cat([r0["out"], r1["out"]]), o.detach().cpu(), 1e-5, "outputs")
+    assert_close(r0["rm"], m.st_gcn_networks[0].tcn[0].running_mean.cpu(), 1e-6, "running_mean")
+    assert_close(r0["rv"], m.st_gcn_networks[2].tcn[3].running_var.cpu(), 1e-6, "running_var")
+    assert_close(r0["dbn_rm"], m.data_bn.running_mean.cpu(), 1e-6, "data_bn running_mean")
+    # per parameter: the mean of the two ranks' gradients is the single-device gradient
+    off = 0
+    from tests.util import feeds_train_bn
+    for name, p in m.named_parameters():
+        n = p.numel()
+        a, b = r0["flat"][off:off + n], want[off:off + n]
+        off += n
+        if feeds_train_bn(name):
+            continue                                              # mathematically zero: rounding noise on both sides
+        assert_close(a, b, 1e-4, name)
 
 
 def test_bench_self_launch_two_ranks():
