@@ -155,6 +155,20 @@ int step_gcn_bwd(const float* dy, const float* dres, const float* x,
                  int N, int Ci, int Co, int K, int T, int stride,
                  void* ws, size_t ws_bytes, void* stream);
 
+/* step_gcn_bwd for a block with an IDENTITY residual (in == out channels, stride 1: `self.residual = lambda x: x`,
+ * classifier.py:170-171): the block input also receives g = id_dout * [id_out > 0] (id_out = the block's output,
+ * id_dout its gradient; relu(tcn(x) + x) of classifier.py:189-191), added to dx in the data kernel's store
+ * where that kernel form exists, by step_masked_add after it otherwise.  id_dout == NULL: step_gcn_bwd.   */
+int step_gcn_bwd_idres(const float* dy, const float* dres, const float* x,
+                       const float* in_scale, const float* in_shift,
+                       const float* w, const float* b, int w_transposed,
+                       const float* A_eff, int a_nnz_max,
+                       const float* res_w, int res_transposed,
+                       const float* id_dout, const float* id_out,
+                       float* dx, float* dw, float* db, float* dA, float* dres_w, float* dres_b,
+                       int N, int Ci, int Co, int K, int T, int stride,
+                       void* ws, size_t ws_bytes, void* stream);
+
 /* ---------------------------------------------------------- temporal convolution ----
  * tcn[2] = Conv2d(C,C,(Kt,1),(s,1),((Kt-1)//2,0)) classifier.py:156-162 and its
  * ConvTranspose2d twin CVAE_stgcn.py:359-365, as an fp32 MFMA implicit GEMM.

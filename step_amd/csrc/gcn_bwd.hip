@@ -32,6 +32,8 @@ struct GbParams {
     const float* A;
     const float* res_w;
     float* dx;
+    const float* id_dout;   // identity residual of the block (Ci == Co, stride 1): dx += id_dout * [id_out > 0]
+    const float* id_out;
     float* part1;     // kernel 1 partials: [nblk][3][EMAX][16]
     float* part2;     // kernel 2 partials: [nblk][3*COPAD*CIP + COPAD*16 + COPAD*CIP + COPAD]
     int w_transposed, res_transposed;
@@ -821,6 +823,22 @@ __global__ __launch_bounds__(512, 2) void gcn_bwd_data16_kernel(GbParams p) {
                     dAk[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(xc[j * 4 + r], dz[k][j][r], dAk[k], 0, 0, 0);
         // dx = SUM_k A_k dz_k along the lanes of the frame
         if (p.dx) {
+            // the block's identity residual (out = relu(.. + x)): its gradient dout * [out > 0] has dx's layout;
+            // the two rows arrive under the rotations (x's registers are free by now)
+            float idg[RES == 0 ? CT * 4 : 1], ido[RES == 0 ? CT * 4 : 1];
+            const bool idres = RES == 0 && p.id_dout != nullptr;
+            if constexpr (RES == 0) {
+                if (idres) {
+                    const __amdgpu_buffer_rsrc_t rg = make_rsrc(p.id_dout + (size_t)nn * CI * p.T * 16);
+                    const __amdgpu_buffer_rsrc_t ro = make_rsrc(p.id_out + (size_t)nn * CI * p.T * 16);
+                    const unsigned so = (unsigned)tt * 64u;
+#pragma unroll
+                    for (int i = 0; i < CT * 4; ++i) {
+                        idg[i] = bload(rg, lane_x, so + (unsigned)((i >> 2) * 16 + (i & 3)) * TS);
+                        ido[i] = bload(ro, lane_x, so + (unsigned)((i >> 2) * 16 + (i & 3)) * TS);
+                    }
+                }
+            }
             float dxr[CT * 4];
 #pragma unroll
             for (int j = 0; j < CT; ++j)
@@ -841,6 +859,12 @@ __global__ __launch_bounds__(512, 2) void gcn_bwd_data16_kernel(GbParams p) {
                     }
                 });
             });
+            if constexpr (RES == 0) {
+                if (idres) {
+#pragma unroll
+                    for (int i = 0; i < CT * 4; ++i) dxr[i] += ido[i] > 0.f ? idg[i] : 0.f;
+                }
+            }
             const __amdgpu_buffer_rsrc_t rs = make_rsrc(p.dx + (size_t)nn * CI * p.T * 16);
             const unsigned so = (unsigned)tt * 64u;
 #pragma unroll
@@ -1755,7 +1779,22 @@ extern "C" int step_gcn_bwd(const float* dy, const float* dres, const float* x, 
                             float* dx, float* dw, float* db, float* dA, float* dres_w, float* dres_b,
                             int N, int Ci, int Co, int K, int T, int stride, void* ws, size_t ws_bytes,
                             void* stream) {
+    return step_gcn_bwd_idres(dy, dres, x, in_scale, in_shift, w, b, w_transposed, A_eff, a_nnz_max, res_w,
+                              res_transposed, nullptr, nullptr, dx, dw, db, dA, dres_w, dres_b, N, Ci, Co, K, T,
+                              stride, ws, ws_bytes, stream);
+}
+
+extern "C" int step_gcn_bwd_idres(const float* dy, const float* dres, const float* x, const float* in_scale,
+                                  const float* in_shift, const float* w, const float* b, int w_transposed,
+                                  const float* A_eff, int a_nnz_max, const float* res_w, int res_transposed,
+                                  const float* id_dout, const float* id_out,
+                                  float* dx, float* dw, float* db, float* dA, float* dres_w, float* dres_b,
+                                  int N, int Ci, int Co, int K, int T, int stride, void* ws, size_t ws_bytes,
+                                  void* stream) {
     STEP_REQUIRE(dy && x && w && A_eff && ws, "step_gcn_bwd: null pointer");
+    STEP_REQUIRE((id_dout == nullptr) == (id_out == nullptr), "step_gcn_bwd: id_dout and id_out come together");
+    STEP_REQUIRE(!id_dout || (dx && !dres && Ci == Co && stride == 1),
+                 "step_gcn_bwd: an identity residual needs dx, Ci == Co, stride 1 and no residual conv");
     STEP_REQUIRE(K >= 1 && K <= 3 && (stride == 1 || stride == 2), "step_gcn_bwd: K=%d stride=%d", K, stride);
     STEP_REQUIRE(a_nnz_max >= 1 && a_nnz_max <= 16, "step_gcn_bwd: a_nnz_max=%d", a_nnz_max);
     STEP_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "step_gcn_bwd: in_scale/in_shift pair");
@@ -1803,6 +1842,10 @@ extern "C" int step_gcn_bwd(const float* dy, const float* dres, const float* x, 
     GbParams p{};
     p.dy = dy; p.dres = dres; p.x = x; p.in_scale = in_scale; p.in_shift = in_shift; p.w = w; p.b = b;
     p.A = A_eff; p.res_w = res_w; p.dx = dx;
+    // the second-form data kernel adds the identity residual's gradient in its dx store; every other form is
+    // followed by the elementwise kernel
+    const bool id_fused = id_dout && v2 && !wide && !small;
+    if (id_fused) { p.id_dout = id_dout; p.id_out = id_out; }
     p.part1 = (float*)ws;
     p.part2 = p.part1 + (size_t)nblk1_ws * g.part1;
     p.w_transposed = w_transposed; p.res_transposed = res_transposed;
@@ -1830,5 +1873,8 @@ extern "C" int step_gcn_bwd(const float* dy, const float* dres, const float* x, 
     f.have_res = dres != nullptr;
     const int total = K * Co * Ci + Co * Ci + Co + K * Co + K * 16;
     hipLaunchKernelGGL(gcn_bwd_finalize_kernel, dim3(step::ceil_div(total, 128)), dim3(128), 0, st, f);
-    return step::check_launch("step_gcn_bwd(finalize)");
+    rc = step::check_launch("step_gcn_bwd(finalize)");
+    if (rc == STEP_OK && id_dout && !id_fused)
+        rc = step_masked_add(id_dout, id_out, dx, 1, (size_t)N * Ci * T * 16, stream);
+    return rc;
 }

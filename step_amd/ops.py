@@ -358,10 +358,10 @@ class StGcnBlockFn(torch.autograd.Function):
         drb = torch.empty(Co, dtype=torch.float32, device=dev) if res_w is not None else None
         nb = _lib.query("step_gcn_bwd_ws_bytes", N, Ci, Co, K, T)
         ws = _ws(nb, dev)
-        _lib.call("step_gcn_bwd", dy, dr, x, s0, h0, gcn_w, gcn_b, int(s.transposed), A_eff, s.nnz,
-                  res_w, int(s.transposed), dx, dgw, dgb, dA, drw, drb, N, Ci, Co, K, T, st, ws, nb)
-        if s.residual == "identity" and dx is not None:
-            _lib.call("step_masked_add", dout, out, dx, 1, dx.numel())
+        idres = s.residual == "identity" and dx is not None        # dx += dout * [out > 0], in the same launch
+        _lib.call("step_gcn_bwd_idres", dy, dr, x, s0, h0, gcn_w, gcn_b, int(s.transposed), A_eff, s.nnz,
+                  res_w, int(s.transposed), dout if idres else None, out if idres else None,
+                  dx, dgw, dgb, dA, drw, drb, N, Ci, Co, K, T, st, ws, nb)
 
         grads = []
         if s.data_bn is not None:

@@ -320,3 +320,28 @@ def test_tcn_const_input(C, Kt, T, transposed, res):
     _lib.call("step_tcn_const_fwd", a0.to(d), wcum, b.to(d), s2.to(d), h2.to(d), dv(r0), dv(sr), dv(hr), 1, out,
               N, C, C, T)
     assert_close(out, ref, TOL, "const-input tcn")
+
+
+@pytest.mark.parametrize("C,T,N", [(64, 9, 3), (32, 20, 2), (128, 6, 2), (16, 7, 2)])
+def test_gcn_bwd_identity_residual_in_the_same_launch(C, T, N):
+    """step_gcn_bwd_idres = step_gcn_bwd followed by dx += dout * [out > 0] (relu(tcn(x) + x), classifier.py:189-191):
+    fused into the data kernel's store at 32 / 64 channels, the elementwise kernel after it elsewhere"""
+    from step_amd import _lib
+    d = dev()
+    g = torch.Generator().manual_seed(13)
+    A = A_spatial(False).to(d)
+    x = torch.randn(N, C, T, 16, generator=g).to(d)
+    w, b = (torch.randn(3 * C, C, generator=g) * 0.2).to(d), torch.randn(3 * C, generator=g).to(d)
+    dy = torch.randn(N, C, T, 16, generator=g).to(d)
+    dout, out = torch.randn(N, C, T, 16, generator=g).to(d), torch.randn(N, C, T, 16, generator=g).to(d)
+    nb = _lib.query("step_gcn_bwd_ws_bytes", N, C, C, 3, T)
+    ws = torch.empty(nb, dtype=torch.uint8, device=d)
+    ref = [torch.empty_like(t) for t in (x, w, b, A)]
+    _lib.call("step_gcn_bwd", dy, None, x, None, None, w, b, 0, A, 4, None, 0, ref[0], ref[1], ref[2], ref[3],
+              None, None, N, C, C, 3, T, 1, ws, nb)
+    ref[0] = ref[0] + dout * (out > 0)
+    got = [torch.empty_like(t) for t in (x, w, b, A)]
+    _lib.call("step_gcn_bwd_idres", dy, None, x, None, None, w, b, 0, A, 4, None, 0, dout, out, got[0], got[1],
+              got[2], got[3], None, None, N, C, C, 3, T, 1, ws, nb)
+    for name, a, r in zip(("dx", "dw", "db", "dA"), got, ref):
+        assert_close(a, r.cpu(), 1e-6, name)
