@@ -121,22 +121,29 @@ __global__ __launch_bounds__(BN_THREADS) void bn_reduce_kernel(
     }
 }
 
-// sums the chunk partials in order; writes fp64 totals [G][2]
-__global__ void bn_sum_chunks_kernel(const double* __restrict__ part, double* __restrict__ tot,
-                                     int G, int nchunks) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= 2 * G) return;
-    // four independent chains (the loads are latency-bound), combined in a fixed order
+// sums the chunk partials in a fixed order; writes fp64 totals [G][2].  A block is 64 entries x 4 chunk
+// quarters, 4 independent chains per thread (the loads are latency-bound: 256 chunks in 16 rounds instead of
+// 64), the quarters combined through LDS
+__global__ __launch_bounds__(256) void bn_sum_chunks_kernel(const double* __restrict__ part, double* __restrict__ tot,
+                                                            int G, int nchunks) {
+    __shared__ double red[4][64];
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + lane;
+    const int ka = nchunks * g / 4, kb = nchunks * (g + 1) / 4;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    int k = 0;
-    for (; k + 3 < nchunks; k += 4) {
-        s0 += part[(size_t)k * G * 2 + e];
-        s1 += part[(size_t)(k + 1) * G * 2 + e];
-        s2 += part[(size_t)(k + 2) * G * 2 + e];
-        s3 += part[(size_t)(k + 3) * G * 2 + e];
+    if (e < 2 * G) {
+        int k = ka;
+        for (; k + 3 < kb; k += 4) {
+            s0 += part[(size_t)k * G * 2 + e];
+            s1 += part[(size_t)(k + 1) * G * 2 + e];
+            s2 += part[(size_t)(k + 2) * G * 2 + e];
+            s3 += part[(size_t)(k + 3) * G * 2 + e];
+        }
+        for (; k < kb; ++k) s0 += part[(size_t)k * G * 2 + e];
     }
-    for (; k < nchunks; ++k) s0 += part[(size_t)k * G * 2 + e];
-    tot[e] = (s0 + s1) + (s2 + s3);
+    red[g][lane] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (g == 0 && e < 2 * G) tot[e] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
 
 __global__ void bn_train_finalize_kernel(const double* __restrict__ tot, const float* __restrict__ gamma,
@@ -398,7 +405,7 @@ extern "C" int step_bn_train_stats(const float* x, int N, int C, int T, int V, i
     double* part = (double*)ws;
     hipLaunchKernelGGL((bn_reduce_kernel<false, 0>), dim3(C, nch), dim3(BN_THREADS), 0, st, x, nullptr,
                        nullptr, nullptr, nullptr, part, N, C, T, V, bn_mode, nch);
-    hipLaunchKernelGGL(bn_sum_chunks_kernel, dim3(step::ceil_div(2 * G, 128)), dim3(128), 0, st, part,
+    hipLaunchKernelGGL(bn_sum_chunks_kernel, dim3(step::ceil_div(2 * G, 64)), dim3(256), 0, st, part,
                        sums, G, nch);
     return step::check_launch("step_bn_train_stats");
 }
@@ -532,7 +539,7 @@ extern "C" int step_bn_bwd_reduce(const float* dy, const float* x, const float* 
     else
         hipLaunchKernelGGL((bn_reduce_kernel<true, 2>), grid, blk, 0, st, x, dy, mask_src, scale, shift,
                            part, N, C, T, V, bn_mode, nch);
-    hipLaunchKernelGGL(bn_sum_chunks_kernel, dim3(step::ceil_div(2 * G, 128)), dim3(128), 0, st, part,
+    hipLaunchKernelGGL(bn_sum_chunks_kernel, dim3(step::ceil_div(2 * G, 64)), dim3(256), 0, st, part,
                        sums, G, nch);
     return step::check_launch("step_bn_bwd_reduce");
 }
@@ -599,8 +606,8 @@ extern "C" int step_bn_bwd_tail_pair(const float* dout, const float* out, const 
     auto coef = [&](char* w) { return (float*)((double*)w + (size_t)BN_MAX_CHUNKS * C * 2 + 2 * (size_t)C); };
     hipLaunchKernelGGL(bn_reduce_pair_kernel, dim3(C, nch), dim3(BN_THREADS), 0, st, dout, out, u, r, part(wsu),
                        part(wsr), N, C, T, nch);
-    hipLaunchKernelGGL(bn_sum_chunks_kernel, dim3(step::ceil_div(2 * C, 128)), dim3(128), 0, st, part(wsu), tot(wsu), C, nch);
-    hipLaunchKernelGGL(bn_sum_chunks_kernel, dim3(step::ceil_div(2 * C, 128)), dim3(128), 0, st, part(wsr), tot(wsr), C, nch);
+    hipLaunchKernelGGL(bn_sum_chunks_kernel, dim3(step::ceil_div(2 * C, 64)), dim3(256), 0, st, part(wsu), tot(wsu), C, nch);
+    hipLaunchKernelGGL(bn_sum_chunks_kernel, dim3(step::ceil_div(2 * C, 64)), dim3(256), 0, st, part(wsr), tot(wsr), C, nch);
     hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3(step::ceil_div(C, 128)), dim3(128), 0, st, tot(wsu), mean_u, invstd_u,
                        gamma_u, training, count, coef(wsu), dgamma_u, dbeta_u, C);
     hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3(step::ceil_div(C, 128)), dim3(128), 0, st, tot(wsr), mean_r, invstd_r,
