@@ -226,6 +226,7 @@ __global__ __launch_bounds__(512) void tcn_wgrad_sw_kernel(WsParams p) {
     // swizzle put them
     const int boffa = l31 * 64 + (((2 * half) + (l31 >> 2)) & 3) * 16;
     const int boffb = l31 * 64 + (((2 * half + 1) + (l31 >> 2)) & 3) * 16;
+    const float relu_lo = p.in_relu ? 0.f : -__builtin_inff();
     float bsc = 1.f, bsh = 0.f;                       // tcn[0] of this lane's input channel
     if (p.in_scale && ci0 + l31 < p.Ci) { bsc = p.in_scale[ci0 + l31]; bsh = p.in_shift[ci0 + l31]; }
 
@@ -261,23 +262,12 @@ __global__ __launch_bounds__(512) void tcn_wgrad_sw_kernel(WsParams p) {
             // instead of one per element (the landed bytes there are the zero line, so 0 * x is 0, not NaN)
             const bool inside = (unsigned)(frame0 + qi) < (unsigned)p.Tin;      // wave-uniform
             float* v = reinterpret_cast<float*>(&f);
-            if constexpr (BF16) {
-                const float sc = inside ? bsc : 0.f, sh = inside ? bsh : 0.f;
+            const float sc = inside ? bsc : 0.f, sh = inside ? bsh : 0.f;
+            // two VALU instructions per element (fma, max: ReLU is a lower bound of 0, or -inf without it); every
+            // VALU instruction of an MFMA wave adds to its MFMA time (fp32 stride-2 wgrad 38.9 -> 37.5 ms against
+            // the four of fma / max / select on in_relu / select on `inside`)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    float x = v[e] * sc + sh;
-                    if (p.in_relu) x = fmaxf(x, 0.f);
-                    v[e] = x;
-                }
-            } else {
-                // (the fp32 mode is MFMA-bound and schedules better with the per-element select: measured)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    float x = v[e] * bsc + bsh;
-                    if (p.in_relu) x = fmaxf(x, 0.f);
-                    v[e] = inside ? x : 0.f;
-                }
-            }
+            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e] * sc + sh, relu_lo);
         };
         frag8 a[TT][MW];
         frag8 b[C::NBT];
