@@ -17,6 +17,7 @@
 // (bit-reproducible).
 #include "common.h"
 #include <type_traits>
+#include <cstdlib>
 
 namespace {
 
@@ -32,6 +33,7 @@ struct WsParams {
     int N, Ci, Co, Tin, Tout, Kt, pad;
     int Q, ntb, nqb, nsplit;
     int ncib;           // input-channel blocks of 32; q-block = (tap block, ci block, co group of 32*MW)
+    int j_base, ks;     // this launch covers taps [j_base, j_base + ks); slab rows are [Ci][ks] (Q = Ci * ks)
 };
 
 template <int MW, int NJ, int STRIDE, int TT>
@@ -85,14 +87,16 @@ __global__ __launch_bounds__(512) void tcn_wgrad_sw_kernel(WsParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
     // blocks that share an XCD (blockIdx % 8) take the q-blocks of the same batch slices
-    int lb = blockIdx.x;
-    if ((gridDim.x & 7) == 0) lb = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    // (blocks go to the XCDs round-robin: XCD x holds gridDim/8 blocks, one more if x < gridDim % 8; its blocks get a
+    // contiguous range of logical ids)
+    const int xcd = blockIdx.x & 7, xfull = gridDim.x >> 3, xrem = gridDim.x & 7;
+    const int lb = xcd * xfull + (xcd < xrem ? xcd : xrem) + (blockIdx.x >> 3);
     const int qb = lb % p.nqb;
     const int split = lb / p.nqb;
     const int tb = qb % p.ntb;                        // tap block
     const int ci0 = ((qb / p.ntb) % p.ncib) * 32;     // input-channel block
     const int co0 = (qb / (p.ntb * p.ncib)) * 32 * MW;   // output-channel group (wide layers: Co > 64)
-    const int j0 = tb * C::TAPS;
+    const int j0 = p.j_base + tb * C::TAPS;
     const int n0 = (int)((long long)p.N * split / p.nsplit);
     const int n1 = (int)((long long)p.N * (split + 1) / p.nsplit);
     const int nchunks = (p.Tout + TT - 1) / TT;
@@ -348,14 +352,22 @@ __global__ __launch_bounds__(512) void tcn_wgrad_sw_kernel(WsParams p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    if (co < p.Co) slab[(size_t)co * p.Q + ci * p.Kt + j] = acc[m][i][r];
+                    if (co < p.Co) slab[(size_t)co * p.Q + ci * p.ks + (j - p.j_base)] = acc[m][i][r];
                 }
         }
     }
 }
 
+// The 75 taps are 15 groups of 5 on blocks of 4 MFMA waves: one launch pads them to 16 groups (the last wave of the
+// last tap block multiplies zeros, 6 % of all MFMAs).  Where it pays, the taps go as TWO launches instead: taps 0..59 as
+// 3 tap blocks of 4 x 5, taps 60..74 as one tap block of 4 x 4 (one padded tap in 76), each with its own number of batch
+// slices so that both fill the 256 CUs (a wave with 4 taps does 4/5 of the work per frame).
+constexpr int TAPS_A = 60, TAPS_B = 16;
+
 struct WsGeom {
     int mw, taps, ntb, nqb, nsplit;
+    bool two;                       // two launches (taps 0..59 | 60..74)
+    int nqbA, nsA, nqbB, nsB;
     size_t ws;
 };
 
@@ -365,11 +377,22 @@ bool ws_geom(int N, int Ci, int Co, int Kt, int stride, WsGeom* g) {
     g->mw = Co == 32 ? 1 : 2;
     g->taps = 20;
     g->ntb = step::ceil_div(Kt, g->taps);
-    g->nqb = g->ntb * (Ci / 32) * (Co / (32 * g->mw));
+    const int per_tb = (Ci / 32) * (Co / (32 * g->mw));
+    g->nqb = g->ntb * per_tb;
     int ns = 256 / g->nqb;                     // one block per CU
     ns = ns < 1 ? 1 : ns;
     g->nsplit = ns < N ? ns : N;
-    g->ws = ((size_t)g->nsplit * Co * Ci * Kt + (size_t)g->nsplit * Co + 16) * 4;   // + a zero line
+    const size_t one = ((size_t)g->nsplit * Co * Ci * Kt + (size_t)g->nsplit * Co + 16) * 4;   // + a zero line
+    g->nqbA = 3 * per_tb;
+    g->nqbB = per_tb;
+    int a = 256 / g->nqbA, b = 256 / g->nqbB;
+    a = a < 1 ? 1 : a; b = b < 1 ? 1 : b;
+    g->nsA = a < N ? a : N;
+    g->nsB = b < N ? b : N;
+    const size_t two = ((size_t)g->nsA * Co * Ci * TAPS_A + (size_t)g->nsB * Co * Ci * TAPS_B + (size_t)g->nsA * Co + 16) * 4;
+    const double cost_one = 1.0 / g->nsplit, cost_two = 1.0 / g->nsA + 0.8 / g->nsB;
+    g->two = cost_two < 0.99 * cost_one;
+    g->ws = one > two ? one : two;
     return true;
 }
 
@@ -387,6 +410,52 @@ int launch_ws(const WsParams& p, hipStream_t st) {
     return step::check_launch("step_tcn_wgrad(sliding)");
 }
 
+template <int NJ>
+int dispatch_ws(const WsParams& p, int mw, int stride, int bf16, hipStream_t st) {
+    if (bf16) {
+        if (mw == 1) return stride == 1 ? launch_ws<1, NJ, 1, 8, true>(p, st) : launch_ws<1, NJ, 2, 6, true>(p, st);
+        return stride == 1 ? launch_ws<2, NJ, 1, 6, true>(p, st) : launch_ws<2, NJ, 2, 6, true>(p, st);
+    }
+    if (mw == 1) return stride == 1 ? launch_ws<1, NJ, 1, 8, false>(p, st) : launch_ws<1, NJ, 2, 6, false>(p, st);
+    return stride == 1 ? launch_ws<2, NJ, 1, 6, false>(p, st) : launch_ws<2, NJ, 2, 6, false>(p, st);
+}
+
+// ordered sums of the two launches' slabs ([nsA][Co][Ci][60] and [nsB][Co][Ci][16]) into dw / db; 4 chains per thread
+__global__ void ws_reduce2_kernel(const float* __restrict__ slabA, const float* __restrict__ slabB,
+                                  const float* __restrict__ dbslab, float* __restrict__ dw, float* __restrict__ db,
+                                  int Co, int Ci, int Kt, int nsA, int nsB, int transposed) {
+    const int total = Co * Ci * Kt;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < total) {
+        const int j = e % Kt, cc = e / Kt;               // cc = co * Ci + ci
+        const bool inA = j < TAPS_A;
+        const float* src = inA ? slabA + (size_t)cc * TAPS_A + j : slabB + (size_t)cc * TAPS_B + (j - TAPS_A);
+        const size_t stride = (size_t)Co * Ci * (inA ? TAPS_A : TAPS_B);
+        const int ns = inA ? nsA : nsB;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int k = 0;
+        for (; k + 3 < ns; k += 4) {
+            s0 += src[(size_t)k * stride];
+            s1 += src[(size_t)(k + 1) * stride];
+            s2 += src[(size_t)(k + 2) * stride];
+            s3 += src[(size_t)(k + 3) * stride];
+        }
+        for (; k < ns; ++k) s0 += src[(size_t)k * stride];
+        const float sum = (s0 + s1) + (s2 + s3);
+        if (!transposed) {
+            dw[e] = sum;
+        } else {
+            const int co = cc / Ci, ci = cc % Ci;
+            dw[((size_t)ci * Co + co) * Kt + (Kt - 1 - j)] = sum;
+        }
+    } else if (e < total + Co && db) {
+        const int co = e - total;
+        float sum = 0.f;
+        for (int k = 0; k < nsA; ++k) sum += dbslab[(size_t)k * Co + co];
+        db[co] = sum;
+    }
+}
+
 }  // namespace
 
 size_t step::wgrad_sw_ws_bytes(int N, int Ci, int Co, int Kt, int stride) {
@@ -402,26 +471,47 @@ int step::wgrad_sw(const float* dout, const float* in, const float* in_scale, co
     if (!ws_geom(N, Ci, Co, Kt, stride, &g) || ws_bytes < g.ws) return 1;
     WsParams p{};
     p.dout = dout; p.in = in; p.in_scale = in_scale; p.in_shift = in_shift; p.in_relu = in_relu;
-    p.slab = (float*)ws;
-    p.dbslab = p.slab + (size_t)g.nsplit * Co * Ci * Kt;
-    float* zl = p.dbslab + (size_t)g.nsplit * Co;
-    if (hipMemsetAsync(zl, 0, 64, st) != hipSuccess) {
-        step::set_error("step_tcn_wgrad: hipMemsetAsync failed");
-        return STEP_ERR_LAUNCH;
-    }
-    p.zeros = zl;
     p.N = N; p.Ci = Ci; p.Co = Co; p.Tin = Tin; p.Tout = Tout; p.Kt = Kt;
     p.pad = (Kt - 1) / 2;
-    p.Q = Ci * Kt; p.ntb = g.ntb; p.nqb = g.nqb; p.nsplit = g.nsplit; p.ncib = Ci / 32;
-    int rc;
-    if (bf16) {
-        if (g.mw == 1) rc = stride == 1 ? launch_ws<1, 5, 1, 8, true>(p, st) : launch_ws<1, 5, 2, 6, true>(p, st);
-        else rc = stride == 1 ? launch_ws<2, 5, 1, 6, true>(p, st) : launch_ws<2, 5, 2, 6, true>(p, st);
-    } else {
-        if (g.mw == 1) rc = stride == 1 ? launch_ws<1, 5, 1, 8, false>(p, st) : launch_ws<1, 5, 2, 6, false>(p, st);
-        else rc = stride == 1 ? launch_ws<2, 5, 1, 6, false>(p, st) : launch_ws<2, 5, 2, 6, false>(p, st);
+    p.ncib = Ci / 32;
+    auto zero_line = [&](float* zl) {
+        if (hipMemsetAsync(zl, 0, 64, st) != hipSuccess) {
+            step::set_error("step_tcn_wgrad: hipMemsetAsync failed");
+            return false;
+        }
+        p.zeros = zl;
+        return true;
+    };
+    // (fp32 only: 37.7 -> 36.6 ms at C = 64, stride 2; the bf16 mode is not bound by its MFMAs and loses: 6.1 -> 6.7 ms)
+    const char* force = getenv("STEP_WS_LAUNCHES");            // "1" | "2": tests and A/B runs
+    const bool two = force ? force[0] == '2' : (g.two && !bf16);
+    if (!two) {
+        p.slab = (float*)ws;
+        p.dbslab = p.slab + (size_t)g.nsplit * Co * Ci * Kt;
+        if (!zero_line(p.dbslab + (size_t)g.nsplit * Co)) return STEP_ERR_LAUNCH;
+        p.j_base = 0; p.ks = Kt;
+        p.Q = Ci * Kt; p.ntb = g.ntb; p.nqb = g.nqb; p.nsplit = g.nsplit;
+        const int rc = dispatch_ws<5>(p, g.mw, stride, bf16, st);
+        if (rc) return rc;
+        return step::wgrad_reduce(p.slab, p.dbslab, dw, db, Co, Ci, Kt, g.nsplit, transposed, st,
+                                  "step_tcn_wgrad(sliding, reduce)");
     }
+    float* slabA = (float*)ws;
+    float* slabB = slabA + (size_t)g.nsA * Co * Ci * TAPS_A;
+    float* dbslab = slabB + (size_t)g.nsB * Co * Ci * TAPS_B;
+    if (!zero_line(dbslab + (size_t)g.nsA * Co)) return STEP_ERR_LAUNCH;
+    // taps 0..59: 3 tap blocks of 4 waves x 5 taps (these blocks also take the bias sums)
+    p.slab = slabA; p.dbslab = dbslab; p.j_base = 0; p.ks = TAPS_A;
+    p.Q = Ci * TAPS_A; p.ntb = 3; p.nqb = g.nqbA; p.nsplit = g.nsA;
+    int rc = dispatch_ws<5>(p, g.mw, stride, bf16, st);
     if (rc) return rc;
-    return step::wgrad_reduce(p.slab, p.dbslab, dw, db, Co, Ci, Kt, g.nsplit, transposed, st,
-                              "step_tcn_wgrad(sliding, reduce)");
+    // taps 60..74: one tap block of 4 waves x 4 taps
+    p.slab = slabB; p.dbslab = nullptr; p.j_base = TAPS_A; p.ks = TAPS_B;
+    p.Q = Ci * TAPS_B; p.ntb = 1; p.nqb = g.nqbB; p.nsplit = g.nsB;
+    rc = dispatch_ws<4>(p, g.mw, stride, bf16, st);
+    if (rc) return rc;
+    const int total = Co * Ci * Kt + Co;
+    hipLaunchKernelGGL(ws_reduce2_kernel, dim3(step::ceil_div(total, 256)), dim3(256), 0, st, slabA, slabB, dbslab,
+                       dw, db, Co, Ci, Kt, g.nsA, g.nsB, transposed);
+    return step::check_launch("step_tcn_wgrad(sliding, reduce of two launches)");
 }

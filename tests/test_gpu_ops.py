@@ -345,3 +345,24 @@ def test_gcn_bwd_identity_residual_in_the_same_launch(C, T, N):
               got[2], got[3], None, None, N, C, C, 3, T, 1, ws, nb)
     for name, a, r in zip(("dx", "dw", "db", "dA"), got, ref):
         assert_close(a, r.cpu(), 1e-6, name)
+
+
+@pytest.mark.parametrize("C,stride,T,N,bf16", [(64, 2, 25, 5, False), (32, 1, 30, 3, False), (64, 1, 18, 4, True),
+                                                (128, 2, 14, 3, False), (32, 2, 21, 7, True)])
+def test_wgrad_two_launch_tap_split(C, stride, T, N, bf16, monkeypatch):
+    """the sliding-window wgrad as two launches (taps 0..59 as 4 x 5 per block, taps 60..74 as 4 x 4: no padded tap
+    group) against the single padded launch, which the oracle tests above pin; the geometry picks it by cost, here
+    both are forced"""
+    from step_amd import ops
+    d = dev()
+    g = torch.Generator().manual_seed(14)
+    To = (T - 1) // stride + 1
+    y = torch.randn(N, C, T, 16, generator=g).to(d)
+    du = torch.randn(N, C, To, 16, generator=g).to(d)
+    sc, sh = (torch.rand(C, generator=g) + 0.5).to(d), torch.randn(C, generator=g).to(d)
+    res = {}
+    for mode in ("1", "2"):
+        monkeypatch.setenv("STEP_WS_LAUNCHES", mode)
+        res[mode] = ops.tcn_wgrad(du, y, sc, sh, True, N, C, C, T, To, 75, stride, False, (C, C, 75, 1), bf16=bf16)
+    assert_close(res["2"][0], res["1"][0].cpu(), 1e-5, "dw")
+    assert_close(res["2"][1], res["1"][1].cpu(), 1e-6, "db")
