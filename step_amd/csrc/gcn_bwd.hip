@@ -755,6 +755,22 @@ __global__ __launch_bounds__(512, 2) void gcn_bwd_data16_kernel(GbParams p) {
                 for (int s = 0; s < S; ++s) drc[s] = bload(rs, lane_dr, so + (unsigned)s * 4u * TOS);
             }
         }
+        // the block's identity residual (out = relu(.. + x)): its gradient dout * [out > 0] has dx's layout; the two
+        // rows are requested with the row's other loads (HBM latency is several times the row's MFMA time)
+        float idg[RES == 0 ? CT * 4 : 1], ido[RES == 0 ? CT * 4 : 1];
+        const bool idres = RES == 0 && p.dx && p.id_dout != nullptr;
+        if constexpr (RES == 0) {
+            if (idres) {
+                const __amdgpu_buffer_rsrc_t rg = make_rsrc(p.id_dout + (size_t)nn * CI * p.T * 16);
+                const __amdgpu_buffer_rsrc_t ro = make_rsrc(p.id_out + (size_t)nn * CI * p.T * 16);
+                const unsigned so = (unsigned)tt * 64u;
+#pragma unroll
+                for (int i = 0; i < CT * 4; ++i) {
+                    idg[i] = bload(rg, lane_x, so + (unsigned)((i >> 2) * 16 + (i & 3)) * TS);
+                    ido[i] = bload(ro, lane_x, so + (unsigned)((i >> 2) * 16 + (i & 3)) * TS);
+                }
+            }
+        }
         if (have_next) {
             int n2 = nn, t2 = tt + 1;
             if (t2 == p.T) { t2 = 0; ++n2; }
@@ -823,22 +839,6 @@ __global__ __launch_bounds__(512, 2) void gcn_bwd_data16_kernel(GbParams p) {
                     dAk[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(xc[j * 4 + r], dz[k][j][r], dAk[k], 0, 0, 0);
         // dx = SUM_k A_k dz_k along the lanes of the frame
         if (p.dx) {
-            // the block's identity residual (out = relu(.. + x)): its gradient dout * [out > 0] has dx's layout;
-            // the two rows arrive under the rotations (x's registers are free by now)
-            float idg[RES == 0 ? CT * 4 : 1], ido[RES == 0 ? CT * 4 : 1];
-            const bool idres = RES == 0 && p.id_dout != nullptr;
-            if constexpr (RES == 0) {
-                if (idres) {
-                    const __amdgpu_buffer_rsrc_t rg = make_rsrc(p.id_dout + (size_t)nn * CI * p.T * 16);
-                    const __amdgpu_buffer_rsrc_t ro = make_rsrc(p.id_out + (size_t)nn * CI * p.T * 16);
-                    const unsigned so = (unsigned)tt * 64u;
-#pragma unroll
-                    for (int i = 0; i < CT * 4; ++i) {
-                        idg[i] = bload(rg, lane_x, so + (unsigned)((i >> 2) * 16 + (i & 3)) * TS);
-                        ido[i] = bload(ro, lane_x, so + (unsigned)((i >> 2) * 16 + (i & 3)) * TS);
-                    }
-                }
-            }
             float dxr[CT * 4];
 #pragma unroll
             for (int j = 0; j < CT; ++j)

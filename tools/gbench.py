@@ -66,6 +66,11 @@ def main():
                                            db, dA, drw, drb, N, Ci, Co, K, T, st, ws, nb),
                          el * (2 * (x.numel() + dy.numel() + (dr.numel() if resconv else 0)) + dx.numel())),
     }
+    if not resconv and Ci == Co:        # identity residual: dx += dout * [out > 0] in the same launch
+        idg, ido = torch.randn(N, Ci, T, 16, generator=g).to(d), torch.randn(N, Ci, T, 16, generator=g).to(d)
+        calls["gcn_bwd_idres"] = (lambda: _lib.call("step_gcn_bwd_idres", dy, dr, x, None, None, w, b, 0, A, nnz, rw, 0,
+                                                     idg, ido, dx, dw, db, dA, drw, drb, N, Ci, Co, K, T, st, ws, nb),
+                                  el * (2 * (x.numel() + dy.numel()) + 3 * dx.numel()))
     # BN / elementwise kernels on the block's (N, Co, T, 16) tensor
     bnw, bnb = torch.ones(Co, device=d), torch.zeros(Co, device=d)
     rm, rv = torch.zeros(Co, device=d), torch.ones(Co, device=d)
