@@ -77,20 +77,28 @@ __device__ __forceinline__ bf16x8 to_bf16(const frag8& f) {
     return __builtin_convertvector(v, bf16x8);
 }
 
+// logical id of a block among the `count` blocks [first, first + count) of a launch: blocks go to the XCDs round-robin
+// (XCD = blockIdx % 8), and the blocks of one XCD get a contiguous range of ids, so that the q-blocks of the same
+// batch slices (consecutive ids) stream their operands out of one L2
+__device__ __forceinline__ int xcd_contiguous_id(int b, int first, int count) {
+    const int x = b & 7;
+    int before = 0;                                   // blocks of this range on the XCDs before x
+    for (int y = 0; y < x; ++y) {
+        const int f = first + ((y - first) & 7);      // first id >= `first` on XCD y
+        before += f < first + count ? (first + count - 1 - f) / 8 + 1 : 0;
+    }
+    const int f = first + ((x - first) & 7);
+    return before + (b - f) / 8;
+}
+
 template <int MW, int NJ, int STRIDE, int TT, bool BF16>
-__global__ __launch_bounds__(512) void tcn_wgrad_sw_kernel(WsParams p) {
+__device__ __forceinline__ void ws_body(const WsParams& p, const int lb, char* smem) {
     using C = WsCfg<MW, NJ, STRIDE, TT>;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    // blocks that share an XCD (blockIdx % 8) take the q-blocks of the same batch slices
-    // (blocks go to the XCDs round-robin: XCD x holds gridDim/8 blocks, one more if x < gridDim % 8; its blocks get a
-    // contiguous range of logical ids)
-    const int xcd = blockIdx.x & 7, xfull = gridDim.x >> 3, xrem = gridDim.x & 7;
-    const int lb = xcd * xfull + (xcd < xrem ? xcd : xrem) + (blockIdx.x >> 3);
     const int qb = lb % p.nqb;
     const int split = lb / p.nqb;
     const int tb = qb % p.ntb;                        // tap block
@@ -358,6 +366,12 @@ __global__ __launch_bounds__(512) void tcn_wgrad_sw_kernel(WsParams p) {
     }
 }
 
+template <int MW, int NJ, int STRIDE, int TT, bool BF16>
+__global__ __launch_bounds__(512) void tcn_wgrad_sw_kernel(WsParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    ws_body<MW, NJ, STRIDE, TT, BF16>(p, xcd_contiguous_id(blockIdx.x, 0, gridDim.x), smem);
+}
+
 // The 75 taps are 15 groups of 5 on blocks of 4 MFMA waves: one launch pads them to 16 groups (the last wave of the
 // last tap block multiplies zeros, 6 % of all MFMAs).  Where it pays, the taps go as TWO launches instead: taps 0..59 as
 // 3 tap blocks of 4 x 5, taps 60..74 as one tap block of 4 x 4 (one padded tap in 76), each with its own number of batch
@@ -503,12 +517,15 @@ int step::wgrad_sw(const float* dout, const float* in, const float* in_scale, co
     // taps 0..59: 3 tap blocks of 4 waves x 5 taps (these blocks also take the bias sums)
     p.slab = slabA; p.dbslab = dbslab; p.j_base = 0; p.ks = TAPS_A;
     p.Q = Ci * TAPS_A; p.ntb = 3; p.nqb = g.nqbA; p.nsplit = g.nsA;
+    // taps 60..74: one tap block of 4 waves x 4 taps
+    WsParams pb = p;
+    pb.slab = slabB; pb.dbslab = nullptr; pb.j_base = TAPS_A; pb.ks = TAPS_B;
+    pb.Q = Ci * TAPS_B; pb.ntb = 1; pb.nqb = g.nqbB; pb.nsplit = g.nsB;
+    // (both ranges as ONE launch - the second behind the first in block order, so that the 4 CUs the 252-block range
+    // leaves free start on it at once - measured the same 36.8 ms: not kept)
     int rc = dispatch_ws<5>(p, g.mw, stride, bf16, st);
     if (rc) return rc;
-    // taps 60..74: one tap block of 4 waves x 4 taps
-    p.slab = slabB; p.dbslab = nullptr; p.j_base = TAPS_A; p.ks = TAPS_B;
-    p.Q = Ci * TAPS_B; p.ntb = 1; p.nqb = g.nqbB; p.nsplit = g.nsB;
-    rc = dispatch_ws<4>(p, g.mw, stride, bf16, st);
+    rc = dispatch_ws<4>(pb, g.mw, stride, bf16, st);
     if (rc) return rc;
     const int total = Co * Ci * Kt + Co;
     hipLaunchKernelGGL(ws_reduce2_kernel, dim3(step::ceil_div(total, 256)), dim3(256), 0, st, slabA, slabB, dbslab,
