@@ -225,6 +225,7 @@ class BlockSpec:
         self.transposed = transposed
         self.nnz = nnz
         self.bn1, self.bn2, self.bnr, self.data_bn = bn1, bn2, bnr, data_bn
+        self.grad_enabled = torch.is_grad_enabled()     # of the caller that builds the spec, right before apply()
 
 
 class StGcnBlockFn(torch.autograd.Function):
@@ -262,7 +263,10 @@ class StGcnBlockFn(torch.autograd.Function):
             # classifier.py:68-78); with data_bn folded into the graph-conv load only the raw x exists
             raise _lib.StepHipError("a first block with an identity residual (in == out channels, stride 1) "
                                     "behind a folded data_bn is not supported")
-        need_grad = any(ctx.needs_input_grad)       # all False under torch.no_grad()
+        # needs_input_grad mirrors tensor.requires_grad whatever the grad mode is: under torch.no_grad() nothing
+        # will be differentiated even though the parameters require grad (and inside forward() the grad mode is
+        # always off, so the caller's mode travels in the spec)
+        need_grad = s.grad_enabled and any(ctx.needs_input_grad)
         dev = x.device
 
         # data_bn statistics (training) or running stats (eval); applied inside the gcn load

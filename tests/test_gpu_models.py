@@ -492,3 +492,24 @@ def test_wide_st_gcn_block_vs_oracle(cin, cout, stride, T, N, mode):
         with torch.no_grad():
             y2, _ = blk(x.to(D), A.to(D))
         assert_close(y2, yo, 1e-4, "fused eval y")
+
+
+def test_eval_under_no_grad_takes_the_fused_epilogue(monkeypatch):
+    """Eval-mode blocks under torch.no_grad() finish inside the temporal conv's epilogue (BN2 + residual + ReLU,
+    classifier.py:189-191) although the parameters require grad; with autograd recording they keep the separate
+    pass.  (ctx.needs_input_grad mirrors requires_grad whatever the grad mode is - this path once never ran.)"""
+    from step_amd import ops
+    from step_amd.net.classifier import Classifier
+    m = Classifier(3, 4, {"strategy": "spatial"})
+    m.load_state_dict(ckpt("ckpt_classifier_real_only_epoch395"))
+    m = m.to(D).eval()
+    x = torch.randn(3, 3, 75, 16, 1, generator=torch.Generator().manual_seed(3)).to(D)
+    calls = []
+    real = ops.affine_act
+    monkeypatch.setattr(ops, "affine_act", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    with torch.no_grad():
+        fused, _ = m(x)
+    assert not calls, "separate BN2 + residual + ReLU pass under no_grad"
+    unfused, _ = m(x)
+    assert len(calls) == 3 and unfused.requires_grad
+    assert_close(fused, unfused.detach(), 1e-5, "fused vs separate epilogue")

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--kt", type=int, default=75)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--bf16", action="store_true", help="bf16-operand MFMA kernels (fp32 tensors)")
+    ap.add_argument("--noact", action="store_true", help="forward conv without BN1 + ReLU on load (A/B of the staging work)")
     a = ap.parse_args()
     d = "cuda:0"
     n, c, s, tin, kt = a.n, a.c, a.stride, a.t, a.kt
@@ -36,8 +37,8 @@ def main():
     wpd = ops.tcn_pack(w, c, c, kt, s, 2, bf16=bf)
     peak = 2500.0 if bf else 157.3
     calls = {
-        "fwd": lambda: ops.tcn_conv(y, sc, sh, True, wp, b, None, None, None, None, None, False,
-                                    n, c, c, tin, tout, kt, s, 0, bf16=bf),
+        "fwd": lambda: ops.tcn_conv(y, None if a.noact else sc, None if a.noact else sh, not a.noact, wp, b, None, None,
+                                    None, None, None, False, n, c, c, tin, tout, kt, s, 0, bf16=bf),
         "dgrad": lambda: ops.tcn_conv(du, None, None, False, wpd, None, None, None, None, None, None,
                                       False, n, c, c, tin, tout, kt, s, 2, bf16=bf),
         "wgrad": lambda: ops.tcn_wgrad(du, y, sc, sh, True, n, c, c, tin, tout, kt, s, False, w.shape, bf16=bf),
