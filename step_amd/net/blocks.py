@@ -63,7 +63,21 @@ class _StBlock(nn.Module):
     def graph_conv(self):
         return self.gctn if self.transposed else self.gcn
 
+    def _refuse_child_hooks(self):
+        """The children are parameter containers: their forward never runs, so a hook on them would silently never
+        fire (GuidedBackprop of utils/processor.py:35,62-66 registers such hooks).  Fail loudly instead."""
+        for name, m in self.named_modules():
+            if m is self:
+                continue
+            if m._forward_hooks or m._forward_pre_hooks or m._backward_hooks or getattr(m, "_backward_pre_hooks", None):
+                from .. import _lib
+                raise _lib.StepHipError(
+                    "a hook is registered on %s.%s, but a step_amd block runs as ONE fused autograd Function and never "
+                    "calls its children: hook the block itself (INTEGRATION.md, 'Hooks on the container children')"
+                    % (type(self).__name__, name))
+
     def forward(self, x, A, data_bn=None):
+        self._refuse_child_hooks()
         ci, co, kt, stride = self._geom
         bnr = self.residual[1] if self._res_kind == "conv" else None
         spec = BlockSpec(ci, co, kt, stride, self._res_kind, self.transposed, self.a_nnz_max,

@@ -157,3 +157,21 @@ def test_gradient_allreduce_two_ranks_gloo(tmp_path):
                          env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "rank0-ok" in out.stdout and "rank1-ok" in out.stdout
+
+
+def test_hooks_on_block_children_are_refused():
+    """GuidedBackprop (utils/processor.py:35,62-66) hooks st_gcn_networks[0].gcn.conv and every block's .relu; those
+    children never run here, so the block refuses instead of silently producing no saliency map"""
+    import pytest
+    import torch
+    from step_amd import _lib
+    from step_amd.net.classifier import Classifier
+    m = Classifier(3, 4, {"strategy": "spatial"})
+    h = m.st_gcn_networks[1].relu.register_forward_hook(lambda mod, i, o: None)
+    with pytest.raises(_lib.StepHipError, match="hook"):
+        m.st_gcn_networks[1](torch.zeros(1, 32, 4, 16), m.A)
+    h.remove()
+    h = m.st_gcn_networks[0].gcn.conv.register_full_backward_hook(lambda mod, gi, go: None)
+    with pytest.raises(_lib.StepHipError, match="gcn.conv"):
+        m.st_gcn_networks[0](torch.zeros(1, 3, 4, 16), m.A)
+    h.remove()
