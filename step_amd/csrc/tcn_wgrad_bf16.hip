@@ -30,3 +30,22 @@ extern "C" int step_tcn_wgrad_bf16(const float* dout, const float* in, const flo
     return step::wgrad_sw(dout, in, in_scale, in_shift, in_relu, dw, db, N, Ci, Co, Tin, Tout, Kt, stride, 0,
                           ws, ws_bytes, (hipStream_t)stream, 1);
 }
+
+// fp32 operands split into bf16 hi + lo, three bf16 MFMAs per product (tcn_wgrad_sw.hip, mode 2): same arguments
+extern "C" int step_tcn_wgrad_split(const float* dout, const float* in, const float* in_scale,
+                                    const float* in_shift, int in_relu, float* dw, float* db, int N, int Ci,
+                                    int Co, int Tin, int Tout, int Kt, int stride, void* ws, size_t ws_bytes,
+                                    void* stream) {
+    STEP_REQUIRE(dout && in && dw && ws, "step_tcn_wgrad_split: null pointer");
+    STEP_REQUIRE(N > 0 && Tin > 0 && (stride == 1 || stride == 2) && Tout == (Tin - 1) / stride + 1,
+                 "step_tcn_wgrad_split: bad shape Tin=%d Tout=%d stride=%d", Tin, Tout, stride);
+    STEP_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "step_tcn_wgrad_split: scale/shift pair");
+    const size_t need = step::wgrad_sw_ws_bytes(N, Ci, Co, Kt, stride);
+    STEP_REQUIRE(need > 0, "step_tcn_wgrad_split: unsupported Ci=%d Co=%d Kt=%d stride=%d", Ci, Co, Kt, stride);
+    if (ws_bytes < need) {
+        step::set_error("step_tcn_wgrad_split: workspace %zu < %zu bytes", ws_bytes, need);
+        return STEP_ERR_WORKSPACE;
+    }
+    return step::wgrad_sw(dout, in, in_scale, in_shift, in_relu, dw, db, N, Ci, Co, Tin, Tout, Kt, stride, 0,
+                          ws, ws_bytes, (hipStream_t)stream, 2);
+}

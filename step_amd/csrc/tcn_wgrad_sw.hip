@@ -77,6 +77,13 @@ __device__ __forceinline__ bf16x8 to_bf16(const frag8& f) {
     return __builtin_convertvector(v, bf16x8);
 }
 
+// v = hi + lo (+ a residual below 2^-17 |v|): hi = bf16(v), lo = bf16(v - hi); v - hi is exact in fp32
+__device__ __forceinline__ void split_bf16(const frag8& f, bf16x8& hi, bf16x8& lo) {
+    const f32x8 v = {f.lo.x, f.lo.y, f.lo.z, f.lo.w, f.hi.x, f.hi.y, f.hi.z, f.hi.w};
+    hi = __builtin_convertvector(v, bf16x8);
+    lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x8), bf16x8);
+}
+
 // logical id of a block among the `count` blocks [first, first + count) of a launch: blocks go to the XCDs round-robin
 // (XCD = blockIdx % 8), and the blocks of one XCD get a contiguous range of ids, so that the q-blocks of the same
 // batch slices (consecutive ids) stream their operands out of one L2
@@ -91,9 +98,11 @@ __device__ __forceinline__ int xcd_contiguous_id(int b, int first, int count) {
     return before + (b - f) / 8;
 }
 
-template <int MW, int NJ, int STRIDE, int TT, bool BF16>
+template <int MW, int NJ, int STRIDE, int TT, int BF>
 __device__ __forceinline__ void ws_body(const WsParams& p, const int lb, char* smem) {
     using C = WsCfg<MW, NJ, STRIDE, TT>;
+    constexpr bool BF16 = BF == 1;       // operands rounded to bf16 (BASELINE's bf16 training config)
+    constexpr bool X3 = BF == 2;         // fp32 operands split into bf16 hi + lo, three bf16 MFMAs per product
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -310,7 +319,23 @@ __device__ __forceinline__ void ws_body(const WsParams& p, const int lb, char* s
                 const int q = STRIDE * (tl + 1) + NJ - STRIDE + s;
                 if (q < C::NBT) b[q] = read_b(q);
             }
-            if constexpr (BF16) {
+            if constexpr (X3) {
+                // split operands: v = hi + lo with hi = bf16(v), lo = bf16(v - hi) (16 mantissa bits together);
+                // a*b ~ a_lo*b_hi + a_hi*b_lo + a_hi*b_hi, the dropped lo*lo term is 2^-16 relative.  Small terms first.
+                bf16x8 ah[MW], al[MW], bh[NJ], bl[NJ];
+#pragma unroll
+                for (int m = 0; m < MW; ++m) split_bf16(a[tl][m], ah[m], al[m]);
+#pragma unroll
+                for (int i = 0; i < NJ; ++i) split_bf16(b[STRIDE * tl + i], bh[i], bl[i]);
+#pragma unroll
+                for (int i = 0; i < NJ; ++i)
+#pragma unroll
+                    for (int m = 0; m < MW; ++m) {
+                        acc[m][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[m], bh[i], acc[m][i], 0, 0, 0);
+                        acc[m][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bl[i], acc[m][i], 0, 0, 0);
+                        acc[m][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bh[i], acc[m][i], 0, 0, 0);
+                    }
+            } else if constexpr (BF16) {
                 // bf16 operands: a lane's eight joints of a frame are one v_mfma_f32_32x32x16_bf16
                 // fragment (k = 8*half + e), rounded here, in registers
                 bf16x8 ab[MW], bb[NJ];
@@ -366,10 +391,10 @@ __device__ __forceinline__ void ws_body(const WsParams& p, const int lb, char* s
     }
 }
 
-template <int MW, int NJ, int STRIDE, int TT, bool BF16>
+template <int MW, int NJ, int STRIDE, int TT, int BF>
 __global__ __launch_bounds__(512) void tcn_wgrad_sw_kernel(WsParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    ws_body<MW, NJ, STRIDE, TT, BF16>(p, xcd_contiguous_id(blockIdx.x, 0, gridDim.x), smem);
+    ws_body<MW, NJ, STRIDE, TT, BF>(p, xcd_contiguous_id(blockIdx.x, 0, gridDim.x), smem);
 }
 
 // The 75 taps are 15 groups of 5 on blocks of 4 MFMA waves: one launch pads them to 16 groups (the last wave of the
@@ -410,10 +435,10 @@ bool ws_geom(int N, int Ci, int Co, int Kt, int stride, WsGeom* g) {
     return true;
 }
 
-template <int MW, int NJ, int STRIDE, int TT, bool BF16>
+template <int MW, int NJ, int STRIDE, int TT, int BF>
 int launch_ws(const WsParams& p, hipStream_t st) {
     using C = WsCfg<MW, NJ, STRIDE, TT>;
-    auto kern = tcn_wgrad_sw_kernel<MW, NJ, STRIDE, TT, BF16>;
+    auto kern = tcn_wgrad_sw_kernel<MW, NJ, STRIDE, TT, BF>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
     if (e != hipSuccess) {
@@ -426,12 +451,16 @@ int launch_ws(const WsParams& p, hipStream_t st) {
 
 template <int NJ>
 int dispatch_ws(const WsParams& p, int mw, int stride, int bf16, hipStream_t st) {
-    if (bf16) {
-        if (mw == 1) return stride == 1 ? launch_ws<1, NJ, 1, 8, true>(p, st) : launch_ws<1, NJ, 2, 6, true>(p, st);
-        return stride == 1 ? launch_ws<2, NJ, 1, 6, true>(p, st) : launch_ws<2, NJ, 2, 6, true>(p, st);
+    if (bf16 == 2) {
+        if (mw == 1) return stride == 1 ? launch_ws<1, NJ, 1, 8, 2>(p, st) : launch_ws<1, NJ, 2, 6, 2>(p, st);
+        return stride == 1 ? launch_ws<2, NJ, 1, 6, 2>(p, st) : launch_ws<2, NJ, 2, 6, 2>(p, st);
     }
-    if (mw == 1) return stride == 1 ? launch_ws<1, NJ, 1, 8, false>(p, st) : launch_ws<1, NJ, 2, 6, false>(p, st);
-    return stride == 1 ? launch_ws<2, NJ, 1, 6, false>(p, st) : launch_ws<2, NJ, 2, 6, false>(p, st);
+    if (bf16) {
+        if (mw == 1) return stride == 1 ? launch_ws<1, NJ, 1, 8, 1>(p, st) : launch_ws<1, NJ, 2, 6, 1>(p, st);
+        return stride == 1 ? launch_ws<2, NJ, 1, 6, 1>(p, st) : launch_ws<2, NJ, 2, 6, 1>(p, st);
+    }
+    if (mw == 1) return stride == 1 ? launch_ws<1, NJ, 1, 8, 0>(p, st) : launch_ws<1, NJ, 2, 6, 0>(p, st);
+    return stride == 1 ? launch_ws<2, NJ, 1, 6, 0>(p, st) : launch_ws<2, NJ, 2, 6, 0>(p, st);
 }
 
 // ordered sums of the two launches' slabs ([nsA][Co][Ci][60] and [nsB][Co][Ci][16]) into dw / db; 4 chains per thread
@@ -498,7 +527,7 @@ int step::wgrad_sw(const float* dout, const float* in, const float* in_scale, co
     };
     // (fp32 only: 37.7 -> 36.6 ms at C = 64, stride 2; the bf16 mode is not bound by its MFMAs and loses: 6.1 -> 6.7 ms)
     const char* force = getenv("STEP_WS_LAUNCHES");            // "1" | "2": tests and A/B runs
-    const bool two = force ? force[0] == '2' : (g.two && !bf16);
+    const bool two = force ? force[0] == '2' : (g.two && bf16 == 0);     // (split operands: 13.0 ms either way)
     if (!two) {
         p.slab = (float*)ws;
         p.dbslab = p.slab + (size_t)g.nsplit * Co * Ci * Kt;

@@ -195,13 +195,13 @@ def tcn_wgrad(dout, inp, in_scale, in_shift, in_relu, N, Ci, Co, Tin, Tout, Kt, 
     dev = dout.device
     dw = torch.empty(wshape, dtype=torch.float32, device=dev)
     db = torch.empty(Co, dtype=torch.float32, device=dev)
-    if bf16:
+    if bf16:                                    # True / "bf16": bf16 operands; "split": fp32 operands as bf16 hi + lo
         nb = _lib.query("step_tcn_wgrad_bf16_ws_bytes", N, Ci, Co, Tin, Tout, Kt, stride)
         if nb == 0 or transposed:
             raise _lib.StepHipError("no bf16 wgrad kernel for C=%d Kt=%d stride=%d" % (Co, Kt, stride))
         ws = _ws(nb, dev)
-        _lib.call("step_tcn_wgrad_bf16", dout, inp, in_scale, in_shift, int(in_relu), dw, db, N, Ci, Co,
-                  Tin, Tout, Kt, stride, ws, nb)
+        _lib.call("step_tcn_wgrad_split" if bf16 == "split" else "step_tcn_wgrad_bf16", dout, inp, in_scale, in_shift,
+                  int(in_relu), dw, db, N, Ci, Co, Tin, Tout, Kt, stride, ws, nb)
         return dw, db
     nb = _lib.query("step_tcn_wgrad_ws_bytes", N, Ci, Co, Tin, Tout, Kt)
     ws = _ws(nb, dev)
@@ -218,9 +218,14 @@ class BlockSpec:
                  bf16=False):
         self.Ci, self.Co, self.Kt, self.stride = Ci, Co, Kt, stride
         # bf16 MFMA operands for the temporal conv where those kernels exist (fp32 otherwise)
-        self.bf16_fwd = bool(bf16) and not transposed and tcn_bf16_supported(Co, Co, Kt, stride, 0)
-        self.bf16_dgrad = bool(bf16) and not transposed and tcn_bf16_supported(Co, Co, Kt, stride, 2)
+        # bf16 == "split": fp32 kernels everywhere except the weight gradient, whose products run as three bf16
+        # MFMAs on split fp32 operands (step_tcn_wgrad_split)
+        split = bf16 == "split"
+        self.bf16_fwd = bool(bf16) and not split and not transposed and tcn_bf16_supported(Co, Co, Kt, stride, 0)
+        self.bf16_dgrad = bool(bf16) and not split and not transposed and tcn_bf16_supported(Co, Co, Kt, stride, 2)
         self.bf16_wgrad = bool(bf16) and not transposed and tcn_wgrad_bf16_supported(Co, Co, Kt, stride)
+        if self.bf16_wgrad and split:
+            self.bf16_wgrad = "split"
         self.residual = residual            # 'none' | 'identity' | 'conv'
         self.transposed = transposed
         self.nnz = nnz

@@ -151,12 +151,16 @@ def test_train_step_kt9_vs_reference(variant):
             assert_grad_close(v, ref1, 1e-4, k, 1e-7)
 
 
-def test_train_step_kt75_ckpt395_vs_reference():
+@pytest.mark.parametrize("mfma", ["f32", "f32_split_wgrad"])
+def test_train_step_kt75_ckpt395_vs_reference(mfma):
+    """(f32_split_wgrad: the weight gradient's products as three bf16 MFMAs on split fp32 operands - held to the
+    same bars against the reference's own gradients)"""
+    import step_amd
     z = load_npz("train_steps")
     d = sub(z, "real_only_k75_ckpt395.")
     m = _variant_model("real_only")
     m.load_state_dict(ckpt("ckpt_classifier_real_only_epoch395"))
-    m = m.to(D).train()
+    m = step_amd.set_mfma_dtype(m.to(D).train(), mfma)
     out, _ = m(d["x"].to(D))
     loss = F.cross_entropy(out, d["labels"].to(D))
     loss.backward()
@@ -345,7 +349,8 @@ def test_batched_prediction_and_feature_export():
     assert np.array_equal(one, labels[:3])
 
 
-def test_five_step_trajectory_vs_reference():
+@pytest.mark.parametrize("mfma", ["f32", "f32_split_wgrad"])
+def test_five_step_trajectory_vs_reference(mfma):
     """processor.py:316-335 over several iterations: 5 x (forward, CrossEntropyLoss, backward, Adam.step) on the
     real_only Classifier (Kt = 75, N = 8, T = 75), lr 0.1 dropped to 0.01 before the 4th step (adjust_lr,
     processor.py:260-268).  Weights are re-packed from the updated parameters every step; loss and train-mode
@@ -354,7 +359,8 @@ def test_five_step_trajectory_vs_reference():
     d = sub(load_npz("trajectory"), "")
     m = _variant_model("real_only")
     m.load_state_dict({k[3:]: v for k, v in d.items() if k.startswith("P0.")})
-    m = m.to(D).train()
+    import step_amd
+    m = step_amd.set_mfma_dtype(m.to(D).train(), mfma)
     opt = torch.optim.Adam(m.parameters(), lr=0.1, weight_decay=1e-4)
     lossf = torch.nn.CrossEntropyLoss()
     for it in range(5):

@@ -366,3 +366,31 @@ def test_wgrad_two_launch_tap_split(C, stride, T, N, bf16, monkeypatch):
         res[mode] = ops.tcn_wgrad(du, y, sc, sh, True, N, C, C, T, To, 75, stride, False, (C, C, 75, 1), bf16=bf16)
     assert_close(res["2"][0], res["1"][0].cpu(), 1e-5, "dw")
     assert_close(res["2"][1], res["1"][1].cpu(), 1e-6, "db")
+
+
+@pytest.mark.parametrize("C,stride,T,N", [(32, 1, 33, 2), (64, 2, 41, 2), (64, 1, 40, 6), (32, 2, 21, 2), (128, 1, 33, 2),
+                                          (64, 2, 240, 16)])
+def test_wgrad_split_operands_vs_oracle(C, stride, T, N):
+    """step_tcn_wgrad_split (three bf16 MFMAs per product on fp32 operands split into bf16 hi + lo) against the fp32
+    oracle at the fp32 bar of the plain kernel (1e-4 of the largest gradient), plus how far it sits from the fp32-MFMA
+    kernel: the dropped lo*lo terms are 2^-16 relative per product"""
+    from step_amd import ops
+    g = torch.Generator().manual_seed(15)
+    y = torch.randn(N, C, T, 16, generator=g) * 1.5 + 0.3
+    w = (torch.randn(C, C, 75, 1, generator=g) * 0.05).requires_grad_(True)
+    b = torch.randn(C, generator=g).requires_grad_(True)
+    sc, sh = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3
+    To = (T - 1) // stride + 1
+    a = torch.relu(y * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    u = stgcn.temporal_conv(a, w, b, stride)
+    du = torch.randn(u.shape, generator=g)
+    u.backward(du)
+    d = dev()
+    args = (du.to(d), y.to(d), sc.to(d), sh.to(d), True, N, C, C, T, To, 75, stride, False, w.shape)
+    dw, db = ops.tcn_wgrad(*args, bf16="split")
+    assert_close(dw, w.grad, TOL, "wgrad (split operands)")
+    assert_close(db, b.grad, TOL, "bgrad")
+    dw32, _ = ops.tcn_wgrad(*args)
+    from tests.util import relerr
+    e_split, e_f32 = relerr(dw, w.grad), relerr(dw32, w.grad)
+    assert e_split < 2e-5, (e_split, e_f32)             # typically 2e-6 .. 6e-6; the fp32-MFMA kernel: ~1e-6

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--kt", type=int, default=75)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--bf16", action="store_true", help="bf16-operand MFMA kernels (fp32 tensors)")
+    ap.add_argument("--split", action="store_true", help="wgrad on split fp32 operands (three bf16 MFMAs per product)")
     ap.add_argument("--noact", action="store_true", help="forward conv without BN1 + ReLU on load (A/B of the staging work)")
     a = ap.parse_args()
     d = "cuda:0"
@@ -41,7 +42,8 @@ def main():
                                     None, None, None, False, n, c, c, tin, tout, kt, s, 0, bf16=bf),
         "dgrad": lambda: ops.tcn_conv(du, None, None, False, wpd, None, None, None, None, None, None,
                                       False, n, c, c, tin, tout, kt, s, 2, bf16=bf),
-        "wgrad": lambda: ops.tcn_wgrad(du, y, sc, sh, True, n, c, c, tin, tout, kt, s, False, w.shape, bf16=bf),
+        "wgrad": lambda: ops.tcn_wgrad(du, y, sc, sh, True, n, c, c, tin, tout, kt, s, False, w.shape,
+                                       bf16="split" if a.split else bf),
     }
     fl = 2.0 * c * c * kt * tout * 16 * n
     for name, fn in calls.items():
