@@ -343,19 +343,21 @@ def main():
                             "fp32 accumulate); logits within 1e-2 of fp32 (tests/test_gpu_bf16.py)"}
         step_amd.set_mfma_dtype(model, "f32")
 
-    # the fp32 step with the weight gradient's products as three bf16 MFMAs on split fp32 operands (opt-in mode,
-    # held to the fp32 parity bars: tests/test_gpu_models.py, tests/test_gpu_ops.py); NOT the headline value
+    # the fp32 step with the temporal kernels' products taken on the bf16 matrix cores from fp32 operands split into
+    # bf16 hi + lo (opt-in modes, held to the fp32 parity bars of the reference fixtures: tests/test_gpu_models.py,
+    # tests/test_gpu_ops.py); reported beside the headline, NEVER as it
     split_run = None
     if args.mfma == "f32" and not args.no_bf16:
-        step_amd.set_mfma_dtype(model, "f32_split_wgrad")
-        k = min(3, args.steps)
-        dts = timed(1, k)
-        split_run = {"sequences_per_s": round(args.batch * world * k / dts, 1),
-                     "ms_per_step": round(dts / k * 1e3, 2), "steps": k,
-                     "note": "same model and step, fp32 everywhere except the temporal conv's weight gradient: its "
-                             "products run as 3 x v_mfma_f32_32x32x16_bf16 on operands split into bf16 hi + lo (16 "
-                             "mantissa bits, fp32 accumulate); loss, outputs and every gradient within the fp32 bars "
-                             "of the reference fixtures"}
+        split_run = {"note": "same model and step on fp32 tensors; products as bf16 MFMA terms on operands split into "
+                             "bf16 hi + lo (16 mantissa bits: hi*hi + hi*lo + lo*hi, the dropped lo*lo is 2^-16 "
+                             "relative), fp32 accumulate; loss, outputs and every gradient of the reference's "
+                             "train-step fixtures hold at the fp32 bars"}
+        for key, mode in (("wgrad_only", "f32_split_wgrad"), ("all_temporal_kernels", "f32_split")):
+            step_amd.set_mfma_dtype(model, mode)
+            k = min(3, args.steps)
+            dts = timed(1, k)
+            split_run[key] = {"mode": mode, "sequences_per_s": round(args.batch * world * k / dts, 1),
+                              "ms_per_step": round(dts / k * 1e3, 2), "steps": k}
         step_amd.set_mfma_dtype(model, "f32")
 
     # forward-only (eval, fused epilogues) rate of the same tensor, for reference
@@ -409,7 +411,7 @@ def main():
             "step_tflops_per_gpu": round(3.0 * model_flops_per_sequence(args.frames) * args.batch * args.steps / dt / 1e12, 2),
             "rehearsal": ("%d ranks share one GPU, collectives over gloo through host memory: not a scaling number"
                           % world) if os.environ.get("STEP_BENCH_REHEARSAL") else None,
-            "bf16_mfma": bf16_run, "f32_split_wgrad": split_run, "roofline": roof, "kernels": kernels, "cpu_baseline": cpu,
+            "bf16_mfma": bf16_run, "f32_split_operands": split_run, "roofline": roof, "kernels": kernels, "cpu_baseline": cpu,
         }
         print(json.dumps(line))
     if world > 1:

@@ -250,12 +250,29 @@ int step_tcn_wgrad_bf16(const float* dout, const float* in, const float* in_scal
                         int N, int Ci, int Co, int Tin, int Tout, int Kt, int stride,
                         void* ws, size_t ws_bytes, void* stream);
 
+/* The split-operand twins of step_tcn_packed_bytes_bf16 / step_tcn_pack_weight_bf16 / step_tcn_conv_bf16: fp32
+ * operands enter the bf16 matrix cores as hi = bf16(v) and lo = bf16(v - hi) (16 mantissa bits); a group is 8 input
+ * channels x {hi, lo} and a tap takes two MFMAs, w_hi * (v_hi + v_lo) and w_lo * v_hi, fp32 accumulate; the dropped
+ * w_lo * v_lo is 2^-16 relative.  Same statements of the reference as step_tcn_conv (classifier.py:156-162 and its
+ * input gradient), same shapes as the bf16 twins, held to the fp32 tolerance of the parity tests.  Opt-in
+ * (step_amd.set_mfma_dtype(model, "f32_split")).                                                            */
+size_t step_tcn_packed_bytes_split(int Co, int Ci, int Kt, int stride, int pack_mode);
+int step_tcn_pack_weight_split(const float* w, void* wp, int Co, int Ci, int Kt, int stride,
+                               int pack_mode, void* stream);
+int step_tcn_conv_split(const float* in, const float* in_scale, const float* in_shift, int in_relu,
+                        const void* wp, const float* bias,
+                        const float* out_scale, const float* out_shift,
+                        const float* res, const float* res_scale, const float* res_shift,
+                        int out_relu, float* out,
+                        int N, int Ci, int Co, int Tin, int Tout, int Kt, int stride, int pack_mode,
+                        void* stream);
+
 /* step_tcn_wgrad with every product taken as THREE bf16 MFMAs on split fp32 operands (v = hi + lo, hi = bf16(v),
  * lo = bf16(v - hi): 16 mantissa bits; a*b ~ a_lo*b_hi + a_hi*b_lo + a_hi*b_hi, fp32 accumulate; the dropped
  * lo*lo term is 2^-16 relative).  Same statement of the reference as step_tcn_wgrad (the weight part of
  * convolution_backward for tcn[2], classifier.py:156-162), same shapes and workspace as step_tcn_wgrad_bf16; held
  * to the fp32 tolerance of the parity tests, at about three times the speed of the fp32-MFMA kernel.  Opt-in
- * (step_amd.set_mfma_dtype(model, "f32_split_wgrad")): whether split-operand products count as fp32 arithmetic is
+ * (step_amd.set_mfma_dtype(model, "f32_split_wgrad" | "f32_split")): whether split-operand products count as fp32 arithmetic is
  * the caller's decision.                                                                                       */
 int step_tcn_wgrad_split(const float* dout, const float* in, const float* in_scale,
                         const float* in_shift, int in_relu, float* dw, float* db,

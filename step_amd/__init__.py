@@ -15,12 +15,12 @@ def set_mfma_dtype(model, dtype):
     """Choose the MFMA operand type of the temporal convolutions of every st_gcn block of `model`:
     "f32" (default; 1e-4 parity with the reference) or "bf16" (BASELINE's bf16 training config:
     operands rounded to bf16 inside the kernels, fp32 accumulation, fp32 tensors and parameters;
-    logits within 1e-2), or "f32_split_wgrad": everything fp32 except the weight gradient of the temporal conv,
-    whose products are taken as three bf16 MFMAs on split fp32 operands (16 mantissa bits, fp32 accumulate; held to
-    the fp32 bars of the parity tests, about three times the fp32-MFMA kernel's speed).  Blocks without a bf16
-    kernel (Kt != 75, 3 channels, st_gctn) stay fp32."""
-    if dtype not in ("f32", "bf16", "f32_split_wgrad"):
-        raise ValueError("mfma dtype must be 'f32', 'bf16' or 'f32_split_wgrad', got %r" % (dtype,))
+    logits within 1e-2), or "f32_split": fp32 operands split into bf16 hi + lo (16 mantissa bits) and every product
+    taken as three bf16 MFMA terms with fp32 accumulation - held to the fp32 bars of the parity tests at about three
+    times the fp32-MFMA kernels' speed ("f32_split_wgrad": only the weight gradient that way).  Blocks without a
+    bf16 kernel (Kt != 75, 3 channels, st_gctn) stay fp32."""
+    if dtype not in ("f32", "bf16", "f32_split", "f32_split_wgrad"):
+        raise ValueError("mfma dtype must be 'f32', 'bf16', 'f32_split' or 'f32_split_wgrad', got %r" % (dtype,))
     from .net.blocks import _StBlock
     for m in model.modules():
         if isinstance(m, _StBlock):

@@ -46,6 +46,9 @@ SIGNATURES = {
     "step_tcn_packed_bytes_bf16": (Z, [I, I, I, I, I]),
     "step_tcn_pack_weight_bf16": (I, [P, P, I, I, I, I, I, P]),
     "step_tcn_conv_bf16": (I, [P, P, P, I, P, P, P, P, P, P, P, I, P, I, I, I, I, I, I, I, I, P]),
+    "step_tcn_packed_bytes_split": (Z, [I, I, I, I, I]),
+    "step_tcn_pack_weight_split": (I, [P, P, I, I, I, I, I, P]),
+    "step_tcn_conv_split": (I, [P, P, P, I, P, P, P, P, P, P, P, I, P, I, I, I, I, I, I, I, I, P]),
     "step_tcn_wgrad_ws_bytes": (Z, [I, I, I, I, I, I]),
     "step_tcn_wgrad": (I, [P, P, P, P, I, P, P, I, I, I, I, I, I, I, I, P, Z, P]),
     "step_tcn_wgrad_bf16_ws_bytes": (Z, [I, I, I, I, I, I, I]),

@@ -47,7 +47,7 @@ struct TbParams {
 
 constexpr int NPROD = 4;          // staging waves per block
 
-template <int NT, int KT2, int STRIDE, int MW, int NW>
+template <int NT, int KT2, int STRIDE, int MW, int NW, bool SPLIT = false>
 struct TbCfg {
     static constexpr int NCONS = MW * NW;                     // MFMA waves
     static constexpr int NTHR = 64 * (NCONS + NPROD);
@@ -60,7 +60,8 @@ struct TbCfg {
     static constexpr int STRIP_BYTES = 16 * CHS;
     static constexpr int STAGE_BYTES = 4 * 32 * 32 * 4;       // output stages: one 32 x 32 tile per MFMA wave
     static constexpr int LDS_BYTES = 2 * STRIP_BYTES + STAGE_BYTES;   // double-buffered strips + stages
-    static constexpr int ITEMS = 16 * ROWS * 4;               // float4 items of one group
+    static constexpr int GCH = SPLIT ? 8 : 16;                // input channels of one group (one MFMA's K = 16)
+    static constexpr int ITEMS = GCH * ROWS * 4;              // float4 items of one group
     static constexpr int SF4 = (ITEMS + PTHR - 1) / PTHR;
     static constexpr int NBTOT = STRIDE * 2 * (NT - 1) + KT2; // B fragments of one group
     static constexpr int NB0 = STRIDE * 2 * (NT - 1) + 1;     // ... needed by tap 0
@@ -75,9 +76,13 @@ struct TbCfg {
 // bring item i+1 (next group, or the next tile's first group) into the other: HBM -> registers
 // -> BN + ReLU -> bf16 -> LDS.  One barrier per item; the two roles never touch the same buffer
 // between barriers, and the staging loads never sit in front of the MFMA waves' operand loads.
-template <int NT, int KT2, int STRIDE, int MW, int NW>
+//
+// SPLIT (fp32 operands at bf16-MFMA speed): a group is 8 channels, each as TWO strip rows - hi = bf16(v) and
+// lo = bf16(v - hi), k = 2*channel + part - and a tap takes two MFMAs: A = [w_hi, w_hi] pairs against (hi, lo) gives
+// w_hi*(v_hi + v_lo), A = [w_lo, 0] gives w_lo*v_hi.  The dropped w_lo*v_lo is 2^-16 relative; fp32 accumulate.
+template <int NT, int KT2, int STRIDE, int MW, int NW, bool SPLIT>
 __global__ __launch_bounds__(64 * (MW * NW + NPROD)) void tcn_bf16_kernel(TbParams p) {
-    using Cfg = TbCfg<NT, KT2, STRIDE, MW, NW>;
+    using Cfg = TbCfg<NT, KT2, STRIDE, MW, NW, SPLIT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
@@ -108,7 +113,7 @@ __global__ __launch_bounds__(64 * (MW * NW + NPROD)) void tcn_bf16_kernel(TbPara
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (f < Cfg::ITEMS && tin >= 0 && tin < p.Tin)
                     v = *reinterpret_cast<const float4*>(
-                        p.in + (((size_t)n * p.Cin + 16 * g + c) * p.Tin + tin) * 16 + (rem & 3) * 4);
+                        p.in + (((size_t)n * p.Cin + Cfg::GCH * g + c) * p.Tin + tin) * 16 + (rem & 3) * 4);
                 sreg[k] = v;
             }
         };
@@ -127,7 +132,7 @@ __global__ __launch_bounds__(64 * (MW * NW + NPROD)) void tcn_bf16_kernel(TbPara
                     f32x4 v = {sreg[k].x, sreg[k].y, sreg[k].z, sreg[k].w};
                     if (tin >= 0 && tin < p.Tin) {
                         if (p.in_scale) {
-                            const float sc = p.in_scale[16 * g + c], sh = p.in_shift[16 * g + c];
+                            const float sc = p.in_scale[Cfg::GCH * g + c], sh = p.in_shift[Cfg::GCH * g + c];
                             v = v * sc + sh;
                         }
                         if (p.in_relu) {
@@ -135,8 +140,15 @@ __global__ __launch_bounds__(64 * (MW * NW + NPROD)) void tcn_bf16_kernel(TbPara
                             v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
                         }
                     }
-                    *reinterpret_cast<bf16x4*>(buf + c * Cfg::CHS + lr * 32 + (rem & 3) * 8) =
-                        __builtin_convertvector(v, bf16x4);
+                    if constexpr (SPLIT) {
+                        const bf16x4 hi = __builtin_convertvector(v, bf16x4);
+                        const bf16x4 lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x4), bf16x4);
+                        *reinterpret_cast<bf16x4*>(buf + (2 * c) * Cfg::CHS + lr * 32 + (rem & 3) * 8) = hi;
+                        *reinterpret_cast<bf16x4*>(buf + (2 * c + 1) * Cfg::CHS + lr * 32 + (rem & 3) * 8) = lo;
+                    } else {
+                        *reinterpret_cast<bf16x4*>(buf + c * Cfg::CHS + lr * 32 + (rem & 3) * 8) =
+                            __builtin_convertvector(v, bf16x4);
+                    }
                 }
             }
         };
@@ -176,10 +188,12 @@ __global__ __launch_bounds__(64 * (MW * NW + NPROD)) void tcn_bf16_kernel(TbPara
                      STRIDE * (2 * wn * NT + ((lane >> 4) & 1)) * 32 + (lane & 3) * 8;
 
     f32x16 acc[NT];
-    constexpr int PFA = 6;      // taps of A-fragment prefetch (L2 latency)
+    constexpr int NS = SPLIT ? 2 : 1;         // A fragments (MFMAs) per tap and column tile
+    constexpr int PFA = SPLIT ? 3 : 6;        // taps of A-fragment prefetch (L2 latency)
     constexpr int PFB = 2;      // taps of B-fragment prefetch (LDS latency)
     auto compute = [&](int g, const char* buf) {
-        const bf16x8* wa = p.wp + ((size_t)g * KT2 * MW + mw) * 64 + lane;
+        // A fragments: [group][tap][set][M tile][lane]
+        const bf16x8* wa = p.wp + ((size_t)g * KT2 * NS * MW + mw) * 64 + lane;
         const char* bb = buf + boff;
         auto read_b = [&](int q) -> bf16x8 {
             const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(bb + q * 32));
@@ -187,23 +201,31 @@ __global__ __launch_bounds__(64 * (MW * NW + NPROD)) void tcn_bf16_kernel(TbPara
                 (lds_bf16x4_ptr)(bb + 4 * Cfg::CHS + q * 32));
             return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
         };
-        bf16x8 a[KT2];
+        bf16x8 a[KT2][NS];
         bf16x8 b[Cfg::NBTOT];
 #pragma unroll
-        for (int m = 0; m < PFA && m < KT2; ++m) a[m] = wa[m * MW * 64];
+        for (int m = 0; m < PFA && m < KT2; ++m)
+#pragma unroll
+            for (int t = 0; t < NS; ++t) a[m][t] = wa[(m * NS + t) * MW * 64];
 #pragma unroll
         for (int q = 0; q < Cfg::NB0 + PFB - 1 && q < Cfg::NBTOT; ++q) b[q] = read_b(q);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < KT2; ++j) {
-            if (j + PFA < KT2) a[j + PFA] = wa[(j + PFA) * MW * 64];
+            if (j + PFA < KT2) {
+#pragma unroll
+                for (int t = 0; t < NS; ++t) a[j + PFA][t] = wa[((j + PFA) * NS + t) * MW * 64];
+            }
             {
                 const int q = Cfg::NB0 + PFB - 1 + j;
                 if (q < Cfg::NBTOT) b[q] = read_b(q);
             }
+            // (split: the small term w_lo * v_hi first, over all column tiles, then w_hi * (v_hi + v_lo))
 #pragma unroll
-            for (int i = 0; i < NT; ++i)
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[j], b[STRIDE * 2 * i + j], acc[i], 0, 0, 0);
+            for (int t = NS - 1; t >= 0; --t)
+#pragma unroll
+                for (int i = 0; i < NT; ++i)
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[j][t], b[STRIDE * 2 * i + j], acc[i], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -266,20 +288,31 @@ __global__ __launch_bounds__(64 * (MW * NW + NPROD)) void tcn_bf16_kernel(TbPara
 }
 
 // A fragments: [group g][tap jj][M tile][lane = 32*h + r][8] = wgen[16g + 8h + e][jj][32*mt + r]
+// split: [group of 8 channels][tap][set][M tile][lane][8], k = 8h + e = 2*channel + part:
+//   set 0 = w_hi for both parts, set 1 = w_lo for part 0 and 0 for part 1
 __global__ void tcn_pack_bf16_kernel(const float* __restrict__ w, __bf16* __restrict__ wp, int Co,
-                                     int Ci, int Kt, int stride, int mode, PackGeom g) {
+                                     int Ci, int Kt, int stride, int mode, PackGeom g, int split) {
     const int mtiles = g.ph * g.cpad / 32;
     const int kt2 = 2 * g.ks;
-    const int total = (g.cin_g / 16) * kt2 * mtiles * 512;
+    const int ns = split ? 2 : 1;
+    const int total = (g.cin_g / (split ? 8 : 16)) * kt2 * ns * mtiles * 512;
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
         const int el = e & 7;
         const int lane = (e >> 3) & 63;
         const int mt = (e >> 9) % mtiles;
-        const int jj = ((e >> 9) / mtiles) % kt2;
-        const int grp = (e >> 9) / (mtiles * kt2);
-        const int cg = 16 * grp + 8 * (lane >> 5) + el;
+        const int set = ((e >> 9) / mtiles) % ns;
+        const int jj = ((e >> 9) / (mtiles * ns)) % kt2;
+        const int grp = (e >> 9) / (mtiles * ns * kt2);
+        const int k = 8 * (lane >> 5) + el;
         const int m = 32 * mt + (lane & 31);
-        wp[e] = (__bf16)pack_value(w, Co, Ci, Kt, stride, mode, g, cg, jj, m);
+        if (!split) {
+            wp[e] = (__bf16)pack_value(w, Co, Ci, Kt, stride, mode, g, 16 * grp + k, jj, m);
+        } else {
+            const float v = pack_value(w, Co, Ci, Kt, stride, mode, g, 8 * grp + (k >> 1), jj, m);
+            const __bf16 hi = (__bf16)v;
+            const __bf16 lo = (__bf16)(v - (float)hi);
+            wp[e] = set == 0 ? hi : ((k & 1) == 0 ? lo : (__bf16)0.f);
+        }
     }
 }
 
@@ -294,9 +327,9 @@ bool bf16_supported(const PackGeom& g, int mode) {
     }
 }
 
-template <int NT, int KT2, int STRIDE, int MW, int NW>
+template <int NT, int KT2, int STRIDE, int MW, int NW, bool SPLIT>
 int launch_tb(const TbParams& p, hipStream_t st) {
-    using Cfg = TbCfg<NT, KT2, STRIDE, MW, NW>;
+    using Cfg = TbCfg<NT, KT2, STRIDE, MW, NW, SPLIT>;
     TbParams q = p;
     q.nRB = step::ceil_div(p.R, Cfg::RB);
     const long long tiles = (long long)p.N * q.nRB;
@@ -304,7 +337,7 @@ int launch_tb(const TbParams& p, hipStream_t st) {
         step::set_error("step_tcn_conv_bf16: %lld tiles out of range", tiles);
         return STEP_ERR_ARG;
     }
-    auto kern = tcn_bf16_kernel<NT, KT2, STRIDE, MW, NW>;
+    auto kern = tcn_bf16_kernel<NT, KT2, STRIDE, MW, NW, SPLIT>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
     int dev = 0, cus = 0;
@@ -322,34 +355,35 @@ int launch_tb(const TbParams& p, hipStream_t st) {
 
 }  // namespace
 
-extern "C" size_t step_tcn_packed_bytes_bf16(int Co, int Ci, int Kt, int stride, int pack_mode) {
+namespace {
+
+size_t packed_bytes(int Co, int Ci, int Kt, int stride, int pack_mode, int split) {
     PackGeom g;
     if (Co < 1 || Ci < 1 || !pack_geom(Co, Ci, Kt, stride, pack_mode, &g)) return 0;
     if (!bf16_supported(g, pack_mode)) return 0;
-    return (size_t)(g.cin_g / 16) * 2 * g.ks * (g.ph * g.cpad / 32) * 512 * 2;
+    return (size_t)(g.cin_g / (split ? 8 : 16)) * 2 * g.ks * (split ? 2 : 1) * (g.ph * g.cpad / 32) * 512 * 2;
 }
 
-extern "C" int step_tcn_pack_weight_bf16(const float* w, void* wp, int Co, int Ci, int Kt, int stride,
-                                         int pack_mode, void* stream) {
+int pack_weight(const float* w, void* wp, int Co, int Ci, int Kt, int stride, int pack_mode, int split,
+                void* stream) {
     PackGeom g;
     STEP_REQUIRE(w && wp, "step_tcn_pack_weight_bf16: null pointer");
     STEP_REQUIRE(Co >= 1 && Ci >= 1 && pack_geom(Co, Ci, Kt, stride, pack_mode, &g) &&
                      bf16_supported(g, pack_mode),
                  "step_tcn_pack_weight_bf16: unsupported Co=%d Ci=%d Kt=%d stride=%d mode=%d", Co, Ci, Kt,
                  stride, pack_mode);
-    const int total = (g.cin_g / 16) * 2 * g.ks * (g.ph * g.cpad / 32) * 512;
+    const int total = (int)(packed_bytes(Co, Ci, Kt, stride, pack_mode, split) / 2);
     const int blocks = step::ceil_div(total, 256) < 1024 ? step::ceil_div(total, 256) : 1024;
     hipLaunchKernelGGL(tcn_pack_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w,
-                       reinterpret_cast<__bf16*>(wp), Co, Ci, Kt, stride, pack_mode, g);
+                       reinterpret_cast<__bf16*>(wp), Co, Ci, Kt, stride, pack_mode, g, split);
     return step::check_launch("step_tcn_pack_weight_bf16");
 }
 
-extern "C" int step_tcn_conv_bf16(const float* in, const float* in_scale, const float* in_shift,
-                                  int in_relu, const void* wp, const float* bias,
-                                  const float* out_scale, const float* out_shift, const float* res,
-                                  const float* res_scale, const float* res_shift, int out_relu,
-                                  float* out, int N, int Ci, int Co, int Tin, int Tout, int Kt,
-                                  int stride, int pack_mode, void* stream) {
+template <bool SPLIT>
+int conv(const float* in, const float* in_scale, const float* in_shift, int in_relu, const void* wp,
+         const float* bias, const float* out_scale, const float* out_shift, const float* res,
+         const float* res_scale, const float* res_shift, int out_relu, float* out, int N, int Ci, int Co,
+         int Tin, int Tout, int Kt, int stride, int pack_mode, void* stream) {
     PackGeom g;
     STEP_REQUIRE(in && wp && out, "step_tcn_conv_bf16: null pointer");
     STEP_REQUIRE(N >= 1 && Ci >= 1 && Co >= 1 && Tin >= 1 && Tout >= 1,
@@ -368,7 +402,7 @@ extern "C" int step_tcn_conv_bf16(const float* in, const float* in_scale, const 
     p.wp = reinterpret_cast<const bf16x8*>(wp); p.bias = bias; p.out_scale = out_scale;
     p.out_shift = out_shift; p.res = res; p.res_scale = res_scale; p.res_shift = res_shift;
     p.out_relu = out_relu; p.out = out; p.N = N; p.Cin = g.cin_g; p.Cout = g.cout_g;
-    p.Cpad = g.cpad; p.PH = g.ph; p.padL = g.padL; p.G = g.cin_g / 16;
+    p.Cpad = g.cpad; p.PH = g.ph; p.padL = g.padL; p.G = g.cin_g / (SPLIT ? 8 : 16);
     const bool dgrad = pack_mode >= 2;
     p.Tin = dgrad ? Tout : Tin;                 // frames of the tensor being read
     p.Tout = dgrad ? Tin : Tout;                // frames of the tensor being written
@@ -377,12 +411,49 @@ extern "C" int step_tcn_conv_bf16(const float* in, const float* in_scale, const 
     const int key = (2 * g.ks) * 100 + g.stride_g * 10 + mw;
     hipStream_t st = (hipStream_t)stream;
     switch (key) {
-        case 7611: return launch_tb<6, 76, 1, 1, 4>(p, st);
-        case 7612: return launch_tb<6, 76, 1, 2, 2>(p, st);
-        case 7622: return launch_tb<5, 76, 2, 2, 2>(p, st);
-        case 3814: return launch_tb<6, 38, 1, 4, 1>(p, st);
+        case 7611: return launch_tb<6, 76, 1, 1, 4, SPLIT>(p, st);
+        case 7612: return launch_tb<6, 76, 1, 2, 2, SPLIT>(p, st);
+        case 7622: return launch_tb<5, 76, 2, 2, 2, SPLIT>(p, st);
+        case 3814: return launch_tb<6, 38, 1, 4, 1, SPLIT>(p, st);
         default: break;
     }
     step::set_error("step_tcn_conv_bf16: no kernel for Kt=%d stride=%d channels=%d", Kt, stride, g.cout_g);
     return STEP_ERR_ARG;
+}
+
+}  // namespace
+
+extern "C" size_t step_tcn_packed_bytes_bf16(int Co, int Ci, int Kt, int stride, int pack_mode) {
+    return packed_bytes(Co, Ci, Kt, stride, pack_mode, 0);
+}
+extern "C" size_t step_tcn_packed_bytes_split(int Co, int Ci, int Kt, int stride, int pack_mode) {
+    return packed_bytes(Co, Ci, Kt, stride, pack_mode, 1);
+}
+
+extern "C" int step_tcn_pack_weight_bf16(const float* w, void* wp, int Co, int Ci, int Kt, int stride,
+                                         int pack_mode, void* stream) {
+    return pack_weight(w, wp, Co, Ci, Kt, stride, pack_mode, 0, stream);
+}
+extern "C" int step_tcn_pack_weight_split(const float* w, void* wp, int Co, int Ci, int Kt, int stride,
+                                          int pack_mode, void* stream) {
+    return pack_weight(w, wp, Co, Ci, Kt, stride, pack_mode, 1, stream);
+}
+
+extern "C" int step_tcn_conv_bf16(const float* in, const float* in_scale, const float* in_shift,
+                                  int in_relu, const void* wp, const float* bias,
+                                  const float* out_scale, const float* out_shift, const float* res,
+                                  const float* res_scale, const float* res_shift, int out_relu,
+                                  float* out, int N, int Ci, int Co, int Tin, int Tout, int Kt,
+                                  int stride, int pack_mode, void* stream) {
+    return conv<false>(in, in_scale, in_shift, in_relu, wp, bias, out_scale, out_shift, res, res_scale, res_shift,
+                       out_relu, out, N, Ci, Co, Tin, Tout, Kt, stride, pack_mode, stream);
+}
+extern "C" int step_tcn_conv_split(const float* in, const float* in_scale, const float* in_shift,
+                                   int in_relu, const void* wp, const float* bias,
+                                   const float* out_scale, const float* out_shift, const float* res,
+                                   const float* res_scale, const float* res_shift, int out_relu,
+                                   float* out, int N, int Ci, int Co, int Tin, int Tout, int Kt,
+                                   int stride, int pack_mode, void* stream) {
+    return conv<true>(in, in_scale, in_shift, in_relu, wp, bias, out_scale, out_shift, res, res_scale, res_shift,
+                      out_relu, out, N, Ci, Co, Tin, Tout, Kt, stride, pack_mode, stream);
 }

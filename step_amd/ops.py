@@ -163,12 +163,13 @@ def tcn_wgrad_bf16_supported(Co, Ci, Kt, stride):
 
 
 def tcn_pack(w, Co, Ci, Kt, stride, mode, bf16=False):
-    if bf16:
-        nb = _lib.query("step_tcn_packed_bytes_bf16", Co, Ci, Kt, stride, mode)
+    if bf16:                                    # True: bf16 operands; "split": fp32 operands as bf16 hi + lo
+        sfx = "split" if bf16 == "split" else "bf16"
+        nb = _lib.query("step_tcn_packed_bytes_" + sfx, Co, Ci, Kt, stride, mode)
         if nb == 0:
             raise _lib.StepHipError("no bf16 temporal kernel for C=%d Kt=%d stride=%d mode=%d" % (Co, Kt, stride, mode))
         wp = torch.empty(nb, dtype=torch.uint8, device=w.device)
-        _lib.call("step_tcn_pack_weight_bf16", w, wp, Co, Ci, Kt, stride, mode)
+        _lib.call("step_tcn_pack_weight_" + sfx, w, wp, Co, Ci, Kt, stride, mode)
         return wp
     n = _lib.query("step_tcn_packed_elems", Co, Ci, Kt, stride, mode)
     if n == 0:
@@ -184,7 +185,8 @@ def tcn_conv(inp, in_scale, in_shift, in_relu, wp, bias, out_scale, out_shift, r
         out = torch.empty((N, Co, Tout, 16), dtype=torch.float32, device=inp.device)
     else:
         out = torch.empty((N, Ci, Tin, 16), dtype=torch.float32, device=inp.device)
-    _lib.call("step_tcn_conv_bf16" if bf16 else "step_tcn_conv", inp, in_scale, in_shift, int(in_relu), wp,
+    fn = "step_tcn_conv_split" if bf16 == "split" else ("step_tcn_conv_bf16" if bf16 else "step_tcn_conv")
+    _lib.call(fn, inp, in_scale, in_shift, int(in_relu), wp,
               bias, out_scale, out_shift, res, res_scale, res_shift, int(out_relu), out, N, Ci, Co, Tin, Tout,
               Kt, stride, mode)
     return out
@@ -218,14 +220,17 @@ class BlockSpec:
                  bf16=False):
         self.Ci, self.Co, self.Kt, self.stride = Ci, Co, Kt, stride
         # bf16 MFMA operands for the temporal conv where those kernels exist (fp32 otherwise)
-        # bf16 == "split": fp32 kernels everywhere except the weight gradient, whose products run as three bf16
-        # MFMAs on split fp32 operands (step_tcn_wgrad_split)
-        split = bf16 == "split"
-        self.bf16_fwd = bool(bf16) and not split and not transposed and tcn_bf16_supported(Co, Co, Kt, stride, 0)
-        self.bf16_dgrad = bool(bf16) and not split and not transposed and tcn_bf16_supported(Co, Co, Kt, stride, 2)
+        # bf16 == "split": fp32 operands as bf16 hi + lo on the bf16 matrix cores (step_tcn_conv_split,
+        # step_tcn_wgrad_split); "split_wgrad": only the weight gradient that way, the two convs on fp32 MFMAs
+        split = bf16 in ("split", "split_wgrad")
+        conv_bf = bf16 if bf16 in (True, "split") else False
+        self.bf16_fwd = bool(conv_bf) and not transposed and tcn_bf16_supported(Co, Co, Kt, stride, 0)
+        self.bf16_dgrad = bool(conv_bf) and not transposed and tcn_bf16_supported(Co, Co, Kt, stride, 2)
         self.bf16_wgrad = bool(bf16) and not transposed and tcn_wgrad_bf16_supported(Co, Co, Kt, stride)
-        if self.bf16_wgrad and split:
-            self.bf16_wgrad = "split"
+        if split:
+            self.bf16_fwd = "split" if self.bf16_fwd else False
+            self.bf16_dgrad = "split" if self.bf16_dgrad else False
+            self.bf16_wgrad = "split" if self.bf16_wgrad else False
         self.residual = residual            # 'none' | 'identity' | 'conv'
         self.transposed = transposed
         self.nnz = nnz

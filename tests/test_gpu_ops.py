@@ -394,3 +394,43 @@ def test_wgrad_split_operands_vs_oracle(C, stride, T, N):
     from tests.util import relerr
     e_split, e_f32 = relerr(dw, w.grad), relerr(dw32, w.grad)
     assert e_split < 2e-5, (e_split, e_f32)             # typically 2e-6 .. 6e-6; the fp32-MFMA kernel: ~1e-6
+
+
+@pytest.mark.parametrize("C,stride,T,N", [(64, 1, 48, 2), (64, 1, 23, 3), (32, 1, 96, 2), (32, 1, 17, 1), (64, 2, 41, 2),
+                                          (64, 2, 240, 1), (32, 1, 240, 1)])
+def test_tcn_split_operands_forward_dgrad_vs_oracle(C, stride, T, N):
+    """step_tcn_conv_split (fp32 operands as bf16 hi + lo, w_hi*(v_hi + v_lo) + w_lo*v_hi on the bf16 matrix cores)
+    against the fp32 oracle at the fp32 bar of the plain kernels: forward with and without the fused epilogue, and
+    the input gradient"""
+    from step_amd import ops
+    from tests.util import relerr
+    Kt = 75
+    g = torch.Generator().manual_seed(16)
+    x = torch.randn(N, C, T, 16, generator=g) * 1.5 + 0.2
+    w = torch.randn(C, C, Kt, 1, generator=g) * 0.05
+    b = torch.randn(C, generator=g)
+    sc, sh = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3
+    To = (T - 1) // stride + 1
+    a = torch.relu(x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)).requires_grad_(True)
+    ref = stgcn.temporal_conv(a, w, b, stride)
+    du = torch.randn(ref.shape, generator=g)
+    ref.backward(du)
+    d = dev()
+    wp = ops.tcn_pack(w.to(d), C, C, Kt, stride, 0, bf16="split")
+    out = ops.tcn_conv(x.to(d), sc.to(d), sh.to(d), True, wp, b.to(d), None, None, None, None, None,
+                       False, N, C, C, T, To, Kt, stride, 0, bf16="split")
+    assert_close(out, ref.detach(), TOL, "split tcn forward")
+    assert relerr(out, ref.detach()) < 2e-5
+    osc, osh = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.2
+    res = torch.randn(N, C, To, 16, generator=g)
+    rsc, rsh = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.2
+    v = lambda t: t.view(1, -1, 1, 1)
+    ref2 = torch.relu(ref.detach() * v(osc) + v(osh) + res * v(rsc) + v(rsh))
+    out2 = ops.tcn_conv(x.to(d), sc.to(d), sh.to(d), True, wp, b.to(d), osc.to(d), osh.to(d),
+                        res.to(d), rsc.to(d), rsh.to(d), True, N, C, C, T, To, Kt, stride, 0, bf16="split")
+    assert_close(out2, ref2, TOL, "split tcn fused epilogue")
+    wpd = ops.tcn_pack(w.to(d), C, C, Kt, stride, 2, bf16="split")
+    da = ops.tcn_conv(du.to(d), None, None, False, wpd, None, None, None, None, None, None, False,
+                      N, C, C, T, To, Kt, stride, 2, bf16="split")
+    assert_close(da, a.grad, TOL, "split dgrad")
+    assert relerr(da, a.grad) < 2e-5

@@ -33,17 +33,17 @@ def main():
     w = (torch.randn(c, c, kt, 1, generator=g) * 0.02).to(d)
     b = torch.zeros(c, device=d)
     sc, sh = torch.ones(c, device=d), torch.zeros(c, device=d)
-    bf = a.bf16
+    bf = "split" if a.split else a.bf16
     wp = ops.tcn_pack(w, c, c, kt, s, 0, bf16=bf)
     wpd = ops.tcn_pack(w, c, c, kt, s, 2, bf16=bf)
-    peak = 2500.0 if bf else 157.3
+    peak = 2500.0 if bf is True else 157.3
     calls = {
         "fwd": lambda: ops.tcn_conv(y, None if a.noact else sc, None if a.noact else sh, not a.noact, wp, b, None, None,
                                     None, None, None, False, n, c, c, tin, tout, kt, s, 0, bf16=bf),
         "dgrad": lambda: ops.tcn_conv(du, None, None, False, wpd, None, None, None, None, None, None,
                                       False, n, c, c, tin, tout, kt, s, 2, bf16=bf),
         "wgrad": lambda: ops.tcn_wgrad(du, y, sc, sh, True, n, c, c, tin, tout, kt, s, False, w.shape,
-                                       bf16="split" if a.split else bf),
+                                       bf16=bf),
     }
     fl = 2.0 * c * c * kt * tout * 16 * n
     for name, fn in calls.items():
