@@ -358,6 +358,17 @@ def main():
             dts = timed(1, k)
             split_run[key] = {"mode": mode, "sequences_per_s": round(args.batch * world * k / dts, 1),
                               "ms_per_step": round(dts / k * 1e3, 2), "steps": k}
+            if mode == "f32_split" and not args.no_infer:
+                model.eval()
+                with torch.no_grad():
+                    model(x)
+                    torch.cuda.synchronize()
+                    ti = time.perf_counter()
+                    for _ in range(3):
+                        model(x)
+                    torch.cuda.synchronize()
+                    split_run[key]["inference_sequences_per_s_per_gpu"] = round(args.batch * 3 / (time.perf_counter() - ti), 1)
+                model.train()
         step_amd.set_mfma_dtype(model, "f32")
 
     # forward-only (eval, fused epilogues) rate of the same tensor, for reference

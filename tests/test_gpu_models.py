@@ -59,9 +59,12 @@ def test_block_vs_reference_golden(fname, tag, mode):
         assert_close(y2, d["y"], 1e-4, "fused eval y")
 
 
-def test_classifier_real_only_ckpt395_eval():
+@pytest.mark.parametrize("mfma", ["f32", "f32_split"])
+def test_classifier_real_only_ckpt395_eval(mfma):
+    import step_amd
     from step_amd.net.classifier import Classifier
     m = _load(Classifier(3, 4, {"strategy": "spatial"}), ckpt("ckpt_classifier_real_only_epoch395")).eval()
+    step_amd.set_mfma_dtype(m, mfma)        # (f32_split: split fp32 operands on the bf16 matrix cores, same bars)
     d = sub(load_npz("classifier_real_only_eval"), "")
     with torch.no_grad():
         probs, feat = m(d["h5_x"].to(D))
