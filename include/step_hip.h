@@ -270,14 +270,15 @@ int step_tcn_conv_split(const float* in, const float* in_scale, const float* in_
 /* step_tcn_wgrad with every product taken as THREE bf16 MFMAs on split fp32 operands (v = hi + lo, hi = bf16(v),
  * lo = bf16(v - hi): 16 mantissa bits; a*b ~ a_lo*b_hi + a_hi*b_lo + a_hi*b_hi, fp32 accumulate; the dropped
  * lo*lo term is 2^-16 relative).  Same statement of the reference as step_tcn_wgrad (the weight part of
- * convolution_backward for tcn[2], classifier.py:156-162), same shapes and workspace as step_tcn_wgrad_bf16; held
+ * convolution_backward for tcn[2], classifier.py:156-162; `transposed` as in step_tcn_wgrad), same shapes and workspace as step_tcn_wgrad_bf16; held
  * to the fp32 tolerance of the parity tests, at about three times the speed of the fp32-MFMA kernel.  Opt-in
  * (step_amd.set_mfma_dtype(model, "f32_split_wgrad" | "f32_split")): whether split-operand products count as fp32 arithmetic is
  * the caller's decision.                                                                                       */
-int step_tcn_wgrad_split(const float* dout, const float* in, const float* in_scale,
-                        const float* in_shift, int in_relu, float* dw, float* db,
-                        int N, int Ci, int Co, int Tin, int Tout, int Kt, int stride,
-                        void* ws, size_t ws_bytes, void* stream);
+int step_tcn_wgrad_split(const float* dout, const float* in,
+                         const float* in_scale, const float* in_shift, int in_relu,
+                         float* dw, float* db,
+                         int N, int Ci, int Co, int Tin, int Tout, int Kt, int stride, int transposed,
+                         void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------- head ----------
  * F.avg_pool2d(x, x.size()[2:]) + mean over M=1, classifier.py:81-82                      */

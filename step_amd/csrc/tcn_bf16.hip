@@ -317,7 +317,7 @@ __global__ void tcn_pack_bf16_kernel(const float* __restrict__ w, __bf16* __rest
 }
 
 bool bf16_supported(const PackGeom& g, int mode) {
-    if (mode != 0 && mode != 2) return false;
+    if (mode < 0 || mode > 3) return false;          // (1 / 3: ConvTranspose2d, stride 1 - same geometry as 0 / 2 there)
     if (g.cin_g % 16 != 0) return false;
     const int mw = g.ph * g.cpad / 32;
     const int key = (2 * g.ks) * 100 + g.stride_g * 10 + mw;

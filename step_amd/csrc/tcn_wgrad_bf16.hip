@@ -34,8 +34,9 @@ extern "C" int step_tcn_wgrad_bf16(const float* dout, const float* in, const flo
 // fp32 operands split into bf16 hi + lo, three bf16 MFMAs per product (tcn_wgrad_sw.hip, mode 2): same arguments
 extern "C" int step_tcn_wgrad_split(const float* dout, const float* in, const float* in_scale,
                                     const float* in_shift, int in_relu, float* dw, float* db, int N, int Ci,
-                                    int Co, int Tin, int Tout, int Kt, int stride, void* ws, size_t ws_bytes,
-                                    void* stream) {
+                                    int Co, int Tin, int Tout, int Kt, int stride, int transposed, void* ws,
+                                    size_t ws_bytes, void* stream) {
+    STEP_REQUIRE(!transposed || stride == 1, "step_tcn_wgrad_split: transposed needs stride 1");
     STEP_REQUIRE(dout && in && dw && ws, "step_tcn_wgrad_split: null pointer");
     STEP_REQUIRE(N > 0 && Tin > 0 && (stride == 1 || stride == 2) && Tout == (Tin - 1) / stride + 1,
                  "step_tcn_wgrad_split: bad shape Tin=%d Tout=%d stride=%d", Tin, Tout, stride);
@@ -46,6 +47,6 @@ extern "C" int step_tcn_wgrad_split(const float* dout, const float* in, const fl
         step::set_error("step_tcn_wgrad_split: workspace %zu < %zu bytes", ws_bytes, need);
         return STEP_ERR_WORKSPACE;
     }
-    return step::wgrad_sw(dout, in, in_scale, in_shift, in_relu, dw, db, N, Ci, Co, Tin, Tout, Kt, stride, 0,
-                          ws, ws_bytes, (hipStream_t)stream, 2);
+    return step::wgrad_sw(dout, in, in_scale, in_shift, in_relu, dw, db, N, Ci, Co, Tin, Tout, Kt, stride,
+                          transposed, ws, ws_bytes, (hipStream_t)stream, 2);
 }

@@ -199,11 +199,15 @@ def tcn_wgrad(dout, inp, in_scale, in_shift, in_relu, N, Ci, Co, Tin, Tout, Kt, 
     db = torch.empty(Co, dtype=torch.float32, device=dev)
     if bf16:                                    # True / "bf16": bf16 operands; "split": fp32 operands as bf16 hi + lo
         nb = _lib.query("step_tcn_wgrad_bf16_ws_bytes", N, Ci, Co, Tin, Tout, Kt, stride)
-        if nb == 0 or transposed:
+        if nb == 0 or (transposed and bf16 != "split"):
             raise _lib.StepHipError("no bf16 wgrad kernel for C=%d Kt=%d stride=%d" % (Co, Kt, stride))
         ws = _ws(nb, dev)
-        _lib.call("step_tcn_wgrad_split" if bf16 == "split" else "step_tcn_wgrad_bf16", dout, inp, in_scale, in_shift,
-                  int(in_relu), dw, db, N, Ci, Co, Tin, Tout, Kt, stride, ws, nb)
+        if bf16 == "split":
+            _lib.call("step_tcn_wgrad_split", dout, inp, in_scale, in_shift, int(in_relu), dw, db, N, Ci, Co, Tin,
+                      Tout, Kt, stride, int(transposed), ws, nb)
+        else:
+            _lib.call("step_tcn_wgrad_bf16", dout, inp, in_scale, in_shift, int(in_relu), dw, db, N, Ci, Co, Tin,
+                      Tout, Kt, stride, ws, nb)
         return dw, db
     nb = _lib.query("step_tcn_wgrad_ws_bytes", N, Ci, Co, Tin, Tout, Kt)
     ws = _ws(nb, dev)
@@ -224,9 +228,11 @@ class BlockSpec:
         # step_tcn_wgrad_split); "split_wgrad": only the weight gradient that way, the two convs on fp32 MFMAs
         split = bf16 in ("split", "split_wgrad")
         conv_bf = bf16 if bf16 in (True, "split") else False
-        self.bf16_fwd = bool(conv_bf) and not transposed and tcn_bf16_supported(Co, Co, Kt, stride, 0)
-        self.bf16_dgrad = bool(conv_bf) and not transposed and tcn_bf16_supported(Co, Co, Kt, stride, 2)
-        self.bf16_wgrad = bool(bf16) and not transposed and tcn_wgrad_bf16_supported(Co, Co, Kt, stride)
+        tr_ok = (not transposed) or split       # st_gctn (ConvTranspose2d) blocks: split modes only
+        m0, m2 = (1, 3) if transposed else (0, 2)
+        self.bf16_fwd = bool(conv_bf) and tr_ok and tcn_bf16_supported(Co, Co, Kt, stride, m0)
+        self.bf16_dgrad = bool(conv_bf) and tr_ok and tcn_bf16_supported(Co, Co, Kt, stride, m2)
+        self.bf16_wgrad = bool(bf16) and tr_ok and tcn_wgrad_bf16_supported(Co, Co, Kt, stride)
         if split:
             self.bf16_fwd = "split" if self.bf16_fwd else False
             self.bf16_dgrad = "split" if self.bf16_dgrad else False

@@ -114,7 +114,8 @@ def test_tcn_bf16_unsupported_shapes_say_so():
     from step_amd import ops
     assert not ops.tcn_bf16_supported(3, 3, 75, 1, 0)
     assert not ops.tcn_bf16_supported(64, 64, 9, 1, 0)
-    assert not ops.tcn_bf16_supported(64, 64, 75, 1, 1)
+    assert ops.tcn_bf16_supported(64, 64, 75, 1, 1)              # ConvTranspose2d forward: stride 1 only
+    assert not ops.tcn_bf16_supported(64, 64, 75, 2, 1)
     assert not ops.tcn_wgrad_bf16_supported(3, 3, 75, 1)
     assert not ops.tcn_wgrad_bf16_supported(64, 64, 9, 1)
 

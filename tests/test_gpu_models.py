@@ -183,11 +183,13 @@ def test_train_step_kt75_ckpt395_vs_reference(mfma):
             assert_grad_close(sd[k[3:]], v, 1e-4, k, 1e-7)
 
 
-def test_cvae_ckpt105_eval_and_train():
+@pytest.mark.parametrize("mfma", ["f32", "f32_split"])
+def test_cvae_ckpt105_eval_and_train(mfma):
+    import step_amd
     from step_amd.net.CVAE_stgcn import CVAE
     m = CVAE(3, 75, 16, 32, 4, {"strategy": "spatial"})
     m.load_state_dict(ckpt("ckpt_cvae_epoch105"))
-    m = m.to(D).eval()
+    m = step_amd.set_mfma_dtype(m.to(D).eval(), mfma)      # (f32_split: the st_gctn ConvTranspose kernels on split operands)
     d = sub(load_npz("cvae_eval"), "", device=D)
     with torch.no_grad():
         mean, lsig = m.encoder(d["x"], d["lenc"])

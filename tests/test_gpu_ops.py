@@ -84,10 +84,12 @@ def test_tcn_dgrad_and_wgrad(C, Kt, stride, T, N):
     assert_close(db, b.grad, TOL, "bgrad")
 
 
-@pytest.mark.parametrize("Ci,Co,Kt,T", [(32, 32, 75, 24), (32, 64, 9, 30), (64, 3, 75, 20)])
-def test_tcn_transposed(Ci, Co, Kt, T):
+@pytest.mark.parametrize("Ci,Co,Kt,T,bf", [(32, 32, 75, 24, False), (32, 64, 9, 30, False), (64, 3, 75, 20, False),
+                                            (32, 32, 75, 24, "split"), (32, 64, 75, 75, "split")])
+def test_tcn_transposed(Ci, Co, Kt, T, bf):
     """ConvTranspose2d twin (CVAE_stgcn.py:359-365): forward, dgrad, wgrad.  In st_gctn the
-    temporal conv is always square (Co x Co); Ci here is ignored except as a label."""
+    temporal conv is always square (Co x Co); Ci here is ignored except as a label.  (bf = "split": the
+    split-operand kernels, same bar.)"""
     from step_amd import ops
     C, N = Co, 2
     g = torch.Generator().manual_seed(3)
@@ -98,16 +100,17 @@ def test_tcn_transposed(Ci, Co, Kt, T):
     du = torch.randn(u.shape, generator=g)
     u.backward(du)
     d = dev()
-    wp = ops.tcn_pack(w.detach().to(d), C, C, Kt, 1, 1)
+    wp = ops.tcn_pack(w.detach().to(d), C, C, Kt, 1, 1, bf16=bf)
     out = ops.tcn_conv(a.detach().to(d), None, None, False, wp, b.detach().to(d), None, None, None, None,
-                       None, False, N, C, C, T, T, Kt, 1, 1)
+                       None, False, N, C, C, T, T, Kt, 1, 1, bf16=bf)
     assert_close(out, u, TOL, "convT fwd")
-    wpd = ops.tcn_pack(w.detach().to(d), C, C, Kt, 1, 3)
+    wpd = ops.tcn_pack(w.detach().to(d), C, C, Kt, 1, 3, bf16=bf)
     da = ops.tcn_conv(du.to(d), None, None, False, wpd, None, None, None, None, None, None, False,
-                      N, C, C, T, T, Kt, 1, 3)
+                      N, C, C, T, T, Kt, 1, 3, bf16=bf)
     assert_close(da, a.grad, TOL, "convT dgrad")
-    dw, db = ops.tcn_wgrad(du.to(d), a.detach().to(d), None, None, False, N, C, C, T, T, Kt, 1, True, w.shape)
+    dw, db = ops.tcn_wgrad(du.to(d), a.detach().to(d), None, None, False, N, C, C, T, T, Kt, 1, True, w.shape, bf16=bf)
     assert_close(dw, w.grad, TOL, "convT wgrad")
+    assert_close(db, b.grad, TOL, "convT bgrad")
 
 
 # --------------------------------------------------------------------------- gcn

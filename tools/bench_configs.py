@@ -25,6 +25,12 @@ sys.path.insert(0, ROOT)
 PEAK_FP32 = 157.3e12
 PEAK_BF16 = 2500.0e12
 D = torch.device("cuda:0")
+MODE = "f32"        # --mfma: step_amd.set_mfma_dtype mode applied to every model below (where it is not set explicitly)
+
+
+def _mode(m):
+    import step_amd
+    return step_amd.set_mfma_dtype(m, MODE) if MODE != "f32" else m
 
 
 def stack_flops(widths, strides, T, kt=75, res=None, K=3, V=16):
@@ -67,7 +73,7 @@ def init_like_reference(m):
 def config2(reps):
     from step_amd.net.classifier import Classifier
     torch.manual_seed(0)
-    m = init_like_reference(Classifier(3, 4, {"strategy": "spatial"})).to(D).eval()
+    m = _mode(init_like_reference(Classifier(3, 4, {"strategy": "spatial"})).to(D).eval())
     n, t = 4096, 240
     x = (torch.randn(n, 3, t, 16, 1, generator=torch.Generator().manual_seed(1234)) * 0.5).to(D)
     with torch.no_grad():
@@ -85,7 +91,7 @@ def config3(reps):
     fl = 3 * stack_flops([(3, 32), (32, 64), (64, 64)], [1, 2, 2], t, res=[False, True, True])
     out = []
     for mode in ("bf16", "f32"):
-        m = init_like_reference(Classifier(3, 4, {"strategy": "spatial"})).to(D).train()
+        m = _mode(init_like_reference(Classifier(3, 4, {"strategy": "spatial"})).to(D).train())
         step_amd.set_mfma_dtype(m, mode)
         opt = torch.optim.Adam(m.parameters(), lr=0.1, weight_decay=1e-4)
         g = torch.Generator().manual_seed(1234)
@@ -109,7 +115,7 @@ def config3(reps):
 def config4(reps):
     from step_amd.net.CVAE_stgcn import CVAE
     torch.manual_seed(0)
-    m = CVAE(3, 75, 16, 32, 4, {"strategy": "spatial"}).to(D).eval()
+    m = _mode(CVAE(3, 75, 16, 32, 4, {"strategy": "spatial"}).to(D).eval())
     n, t = 2048, 75
     z = (torch.randn(n, 32, generator=torch.Generator().manual_seed(5)) * 3 - 1.5).to(D)     # processor_stgcn.py:319
     l = F.one_hot(torch.arange(n) % 4, 4).float().to(D)
@@ -133,7 +139,7 @@ def cvae_train(reps):
     from step_amd import losses
     from step_amd.net.CVAE_stgcn import CVAE
     torch.manual_seed(0)
-    m = CVAE(3, 75, 16, 32, 4, {"strategy": "spatial"}).to(D).train()
+    m = _mode(CVAE(3, 75, 16, 32, 4, {"strategy": "spatial"}).to(D).train())
     opt = torch.optim.Adam(m.parameters(), lr=0.1, weight_decay=1e-4)
     n, t = 1024, 75
     g = torch.Generator().manual_seed(3)
@@ -156,7 +162,7 @@ def cvae_train(reps):
 def config5(reps):
     from step_amd.net.classifier_hybrid import Classifier
     torch.manual_seed(0)
-    m = init_like_reference(Classifier(3, 27, 4, {"strategy": "spatial"})).to(D).eval()
+    m = _mode(init_like_reference(Classifier(3, 27, 4, {"strategy": "spatial"})).to(D).eval())
     n, t = 1024, 1024
     g = torch.Generator().manual_seed(9)
     xa = (torch.rand(n, 27, generator=g) * 2 - 1).to(D)
@@ -181,7 +187,7 @@ def kt9(reps):
     y = torch.randint(0, 4, (n,), generator=g).to(D)
     fl = stack_flops([(3, 32), (32, 64), (64, 64)], [1, 2, 1], t, kt=9)
     out = []
-    m = init_like_reference(Classifier(3, 4, {"strategy": "spatial"}, temporal_kernel_size=9)).to(D).eval()
+    m = _mode(init_like_reference(Classifier(3, 4, {"strategy": "spatial"}, temporal_kernel_size=9)).to(D).eval())
     with torch.no_grad():
         dt = timeit(lambda: m(x), reps)
     out.append({"config": "Kt=9 real_only inference N=4096 x 3 x 240 x 16 fp32 eval", "sequences_per_s": n / dt, "ms": dt * 1e3,
@@ -222,11 +228,16 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--only", default="2,3,4,5")
+    ap.add_argument("--mfma", default="f32", help="f32 | f32_split | f32_split_wgrad for the configs that do not fix it")
     a = ap.parse_args()
     torch.cuda.set_device(D)
+    global MODE
+    MODE = a.mfma
     for k in a.only.split(","):
         r = {"2": config2, "3": config3, "4": config4, "5": config5, "aff": aff, "kt9": kt9, "cvae_train": cvae_train}[k](a.reps)
         for line in (r if isinstance(r, list) else [r]):
+            if MODE != "f32":
+                line["mfma"] = MODE
             print(json.dumps({k2: (round(v, 4) if isinstance(v, float) else v) for k2, v in line.items()}), flush=True)
 
 
