@@ -255,7 +255,8 @@ __device__ __forceinline__ void ws_body(const WsParams& p, const int lb, char* s
     // registers) are the first NJ - S of the next chunk of the same sequence - carried over instead of being read
     // from the ring and activated again before the chunk's first MFMA can issue
     // (bf16 mode only: 6.6 / 5.9 -> 6.4 / 5.7 ms; the fp32 mode schedules worse with it: 36.7 -> 37.3 ms, measured)
-    constexpr int NCARRY = (BF16 && NJ - STRIDE > 0 && NJ <= C::NBT) ? NJ - STRIDE : 0;
+    // (split mode: stride 1 only - 11.6 / 7.0 -> 11.3 / 6.7 ms there, 13.0 -> 13.6 ms at stride 2, measured)
+    constexpr int NCARRY = ((BF == 1 || (BF == 2 && STRIDE == 1)) && NJ - STRIDE > 0 && NJ <= C::NBT) ? NJ - STRIDE : 0;
     frag8 bcar[NCARRY > 0 ? NCARRY : 1];
     for (int it = 0; it < total; ++it) {
         const int cc = it % nchunks;
