@@ -267,7 +267,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-kernels", action="store_true")
     ap.add_argument("--no-infer", action="store_true")
-    ap.add_argument("--mfma", choices=["f32", "bf16"], default="f32",
+    ap.add_argument("--mfma", choices=["f32", "bf16", "f32_split", "f32_split_wgrad", "f32_split_gcn"], default="f32",
                     help="MFMA operand type of the temporal convs for the headline number (f32 = BASELINE "
                          "configs[1]); with f32 a short bf16-operand run is reported beside it")
     ap.add_argument("--no-bf16", action="store_true", help="skip the secondary bf16-operand run")
@@ -352,13 +352,14 @@ def main():
                              "bf16 hi + lo (16 mantissa bits: hi*hi + hi*lo + lo*hi, the dropped lo*lo is 2^-16 "
                              "relative), fp32 accumulate; loss, outputs and every gradient of the reference's "
                              "train-step fixtures hold at the fp32 bars"}
-        for key, mode in (("wgrad_only", "f32_split_wgrad"), ("all_temporal_kernels", "f32_split")):
+        for key, mode in (("wgrad_only", "f32_split_wgrad"), ("all_temporal_kernels", "f32_split"),
+                          ("temporal_and_graph_conv_fwd", "f32_split_gcn")):
             step_amd.set_mfma_dtype(model, mode)
             k = min(3, args.steps)
             dts = timed(1, k)
             split_run[key] = {"mode": mode, "sequences_per_s": round(args.batch * world * k / dts, 1),
                               "ms_per_step": round(dts / k * 1e3, 2), "steps": k}
-            if mode == "f32_split" and not args.no_infer:
+            if mode != "f32_split_wgrad" and not args.no_infer:
                 model.eval()
                 with torch.no_grad():
                     model(x)
@@ -415,7 +416,10 @@ def main():
                                    "N=%d x 3 x %d x 16 per GPU, fp32 tensors%s; step = train-mode fwd + "
                                    "CrossEntropy + bwd + grad all-reduce + Adam"
                                    % (args.batch, args.frames,
-                                      ", bf16 MFMA operands in the temporal convs" if args.mfma == "bf16" else ""),
+                                      {"bf16": ", bf16 MFMA operands in the temporal convs",
+                                       "f32_split": ", fp32 operands as bf16 hi + lo on the bf16 matrix cores",
+                                       "f32_split_gcn": ", fp32 operands as bf16 hi + lo on the bf16 matrix cores (graph-conv forward too)",
+                                       "f32_split_wgrad": ", wgrad operands as bf16 hi + lo"}.get(args.mfma, "")),
                        "global_batch": args.batch * world, "frames": args.frames,
                        "parallelism": "dp%d%s" % (world, "+syncbn" if args.sync_bn and world > 1 else "")},
             "inference_sequences_per_s_per_gpu": round(infer, 1),

@@ -141,6 +141,15 @@ int step_gcn_fwd(const float* x, const float* in_scale, const float* in_shift,
                  const float* A_eff, int a_nnz_max, float* y,
                  const float* res_w, const float* res_b, int res_transposed, float* res_out,
                  int N, int Ci, int Co, int K, int T, int stride, void* stream);
+/* step_gcn_fwd with both contractions on the bf16 matrix cores, every fp32 operand (x, A_eff, w, the aggregated
+ * z) as bf16 hi + lo and the lo * lo term dropped (about 2^-16 relative per product, fp32 accumulation): the
+ * graph-conv half of the opt-in "f32_split" mode.  Same arguments and layouts.  Covers Ci % 16 == 0, Co % 32 == 0,
+ * both <= 256, no data_bn; any other layer (the first block) runs step_gcn_fwd's fp32 kernels unchanged.       */
+int step_gcn_fwd_split(const float* x, const float* in_scale, const float* in_shift,
+                       const float* w, const float* b, int w_transposed,
+                       const float* A_eff, int a_nnz_max, float* y,
+                       const float* res_w, const float* res_b, int res_transposed, float* res_out,
+                       int N, int Ci, int Co, int K, int T, int stride, void* stream);
 
 /* backward of the above (K16 of SURVEY 2.2).  Any of dx, dw/db, dA, dres_w/dres_b may be
  * NULL.  dA is returned on the support of A_eff only (d importance = A * dA needs no more).

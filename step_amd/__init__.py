@@ -19,8 +19,8 @@ def set_mfma_dtype(model, dtype):
     taken as three bf16 MFMA terms with fp32 accumulation - held to the fp32 bars of the parity tests at about three
     times the fp32-MFMA kernels' speed ("f32_split_wgrad": only the weight gradient that way).  Blocks without a
     bf16 kernel (Kt != 75, 3 channels; st_gctn blocks in the "bf16" mode) stay fp32."""
-    if dtype not in ("f32", "bf16", "f32_split", "f32_split_wgrad"):
-        raise ValueError("mfma dtype must be 'f32', 'bf16', 'f32_split' or 'f32_split_wgrad', got %r" % (dtype,))
+    if dtype not in ("f32", "bf16", "f32_split", "f32_split_wgrad", "f32_split_gcn"):
+        raise ValueError("mfma dtype must be 'f32', 'bf16', 'f32_split', 'f32_split_wgrad' or 'f32_split_gcn', got %r" % (dtype,))
     from .net.blocks import _StBlock
     for m in model.modules():
         if isinstance(m, _StBlock):

@@ -33,6 +33,7 @@ SIGNATURES = {
     "step_bn_bwd_tail_pair": (I, [P, P, P, P, P, P, P, P, P, P, I, P, P, P, P, P, P, I, I, I, I, P, Z, P]),
     "step_masked_add": (I, [P, P, P, I, Z, P]),
     "step_gcn_fwd": (I, [P, P, P, P, P, I, P, I, P, P, P, I, P, I, I, I, I, I, I, P]),
+    "step_gcn_fwd_split": (I, [P, P, P, P, P, I, P, I, P, P, P, I, P, I, I, I, I, I, I, P]),
     "step_gcn_bwd_ws_bytes": (Z, [I, I, I, I, I]),
     "step_gcn_bwd": (I, [P, P, P, P, P, P, P, I, P, I, P, I, P, P, P, P, P, P,
                          I, I, I, I, I, I, P, Z, P]),

@@ -730,6 +730,185 @@ __global__ __launch_bounds__(512, 2) void gcn_fwd16_kernel(GcnParams p) {
     }
 }
 
+// Split-operand twin of gcn_fwd16_kernel (step_amd.set_mfma_dtype "f32_split"): the four k-steps of every
+// 16x16x4 chain become TWO v_mfma_f32_16x16x32_bf16 on operands split into bf16 hi + lo (any pairing of k works as
+// long as A and B agree).  W lies in LDS already split ([.][lane][COT] x (hi4, lo4), the fp32 image's size); x and
+// the aggregation's result are split in registers once and reused by every partition / output tile.
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+// A-role operand: (hi[4], lo[4]) along k; B-role operand: (hi, hi) and (lo, 0).  With K = 32 per instruction
+// (v_mfma_f32_16x16x32_bf16, the full-rate shape; lane (q, .) holds k = 8q .. 8q+7 = the four k-steps x {hi, lo}):
+//   (a_hi, a_lo) . (b_hi, b_hi) = a_hi*b_hi + a_lo*b_hi      (a_hi, a_lo) . (b_lo, 0) = a_hi*b_lo
+struct SplitA { bf16x8_t hl; };
+struct SplitB { bf16x8_t hh, l0; };
+__device__ __forceinline__ SplitA split_a(const f32x4 v) {
+    const bf16x4_t h = __builtin_convertvector(v, bf16x4_t);
+    const bf16x4_t l = __builtin_convertvector(v - __builtin_convertvector(h, f32x4), bf16x4_t);
+    return SplitA{__builtin_shufflevector(h, l, 0, 1, 2, 3, 4, 5, 6, 7)};
+}
+__device__ __forceinline__ SplitB split_b(const f32x4 v) {
+    const bf16x4_t h = __builtin_convertvector(v, bf16x4_t);
+    const bf16x4_t l = __builtin_convertvector(v - __builtin_convertvector(h, f32x4), bf16x4_t);
+    const bf16x4_t z = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+    return SplitB{__builtin_shufflevector(h, h, 0, 1, 2, 3, 0, 1, 2, 3), __builtin_shufflevector(l, z, 0, 1, 2, 3, 4, 5, 6, 7)};
+}
+__device__ __forceinline__ f32x4 mfma_split(const SplitA& a, const SplitB& b, f32x4 c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.hl, b.l0, c, 0, 0, 0);        // the small term first
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.hl, b.hh, c, 0, 0, 0);
+}
+
+// RES: 0 no residual conv, 1 residual conv at stride 1, 2 at stride 2 (even frames only)
+template <int COT, int RES>
+__global__ __launch_bounds__(512, 1) void gcn_fwd16s_kernel(GcnParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int FR = 4;                                  // frames per work unit (256 contiguous bytes per stored row)
+    const int CIT = p.Ci / 16;
+    constexpr int NP = RES ? 4 : 3;
+    constexpr int FRR = RES == 2 ? FR / 2 : (RES ? FR : 1);
+    SplitA* Wl = reinterpret_cast<SplitA*>(smem);          // [NP][CIT][COT][64 lanes]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = lane >> 4, l16 = lane & 15;
+    const int co0 = blockIdx.y * 16 * COT;
+    // per-wave output stage behind the W image: [16 channels][FR frames][16 joints]
+    float* stg = smem + (size_t)NP * CIT * 64 * COT * 4 + (size_t)wave * 16 * FR * 16;
+
+    for (int e = tid; e < NP * CIT * 64 * COT; e += 512) {
+        const int ln = e & 63, ct = (e >> 6) % COT, tile = (e / (COT * 64)) % CIT, kk = e / (COT * 64 * CIT);
+        const int c = co0 + 16 * ct + (ln & 15);
+        f32x4 v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ci = 16 * tile + 4 * (ln >> 4) + r;
+            float x = 0.f;
+            if (kk < 3) {
+                if (kk < p.K)
+                    x = p.w_transposed ? p.w[(size_t)ci * (p.K * p.Co) + kk * p.Co + c] : p.w[((size_t)kk * p.Co + c) * p.Ci + ci];
+            } else {
+                x = p.res_transposed ? p.res_w[(size_t)ci * p.Co + c] : p.res_w[(size_t)c * p.Ci + ci];
+            }
+            v[r] = x;
+        }
+        Wl[e] = split_a(v);
+    }
+    SplitB ak[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            v[e] = k < 3 ? ((k < p.K) ? p.A[(k * 16 + 4 * q + e) * 16 + l16] : 0.f) : ((4 * q + e == l16) ? 1.f : 0.f);
+        ak[k] = split_b(v);
+    }
+    // bias term of output channel c, joint w: SUM_k b[k,c] colsum(A_k)[w]; kept in LDS, read at the flush
+    float* bias = smem + (size_t)NP * CIT * 64 * COT * 4 + 8 * 16 * FR * 16;    // [16 COT][16], then res bias [16 COT]
+    for (int e = tid; e < 16 * COT * 16; e += 512) {
+        const int c = co0 + (e >> 4), w = e & 15;
+        float s = 0.f;
+        if (p.b)
+            for (int kk = 0; kk < p.K; ++kk) {
+                float cs = 0.f;
+                for (int v = 0; v < 16; ++v) cs += p.A[(kk * 16 + v) * 16 + w];
+                s += p.b[kk * p.Co + c] * cs;
+            }
+        bias[e] = s;
+    }
+    for (int e = tid; e < 16 * COT; e += 512) bias[16 * COT * 16 + e] = (RES && p.res_b) ? p.res_b[co0 + e] : 0.f;
+    __syncthreads();
+
+    // work unit: FR consecutive frames of one sequence (the last unit of a sequence may be short)
+    const int gps = (p.T + FR - 1) / FR;
+    const long long G = (long long)p.N * gps;
+    const long long nw = (long long)gridDim.x * 8, gw = (long long)blockIdx.x * 8 + wave;
+    const long long g0 = G * gw / nw, g1 = G * (gw + 1) / nw;
+    const int ngrp = (int)(g1 - g0);
+    int n = (int)(g0 / gps), tg = (int)(g0 - (long long)n * gps);
+    const unsigned TS = (unsigned)p.T * 64u, TOS = (unsigned)p.To * 64u;
+    const unsigned lane_x = (unsigned)l16 * TS + q * 16u;
+    const SplitA* wl = Wl + lane;
+
+    // stage -> HBM for one 16-channel tile: 16-byte pieces, FR * 64 contiguous bytes per channel row
+    auto flush = [&](float* base, unsigned row_bytes, int c_first, int f0, int nf) {
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(base);
+#pragma unroll
+        for (int it = 0; it < 16 * FR * 4 / 64; ++it) {
+            const int idx = it * 64 + lane;
+            const int c = idx >> 4, piece = idx & 15;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(stg + c * (FR * 16) + piece * 4);
+            if ((piece >> 2) < nf)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs,
+                                                       (int)((unsigned)(c_first + c) * row_bytes + (unsigned)piece * 16u),
+                                                       (int)((unsigned)f0 * 64u), 0);
+        }
+    };
+
+    for (int i = 0; i < ngrp; ++i) {
+        const int t0 = tg * FR;
+        const int nf = p.T - t0 < FR ? p.T - t0 : FR;
+        const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x + (size_t)n * p.Ci * p.T * 16);
+        f32x4 acc[FR][COT], accr[FRR][COT];
+#pragma unroll
+        for (int f = 0; f < FR; ++f)
+#pragma unroll
+            for (int ct = 0; ct < COT; ++ct) acc[f][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int f = 0; f < FRR; ++f)
+#pragma unroll
+            for (int ct = 0; ct < COT; ++ct) accr[f][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int tile = 0; tile < CIT; ++tile) {
+            f32x4 xq[FR];
+#pragma unroll
+            for (int f = 0; f < FR; ++f) {
+                const int tt = t0 + f < p.T ? t0 + f : p.T - 1;
+                xq[f] = bload4(rx, lane_x, (unsigned)tt * 64u + (unsigned)tile * 16u * TS);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (k == 3 && !RES) break;
+                SplitA w[COT];
+#pragma unroll
+                for (int ct = 0; ct < COT; ++ct) w[ct] = wl[(size_t)((k * CIT + tile) * COT + ct) * 64];
+#pragma unroll
+                for (int f = 0; f < FR; ++f) {
+                    // (residual conv at stride 2: odd frames are not outputs; t0 is a multiple of 4)
+                    if (k == 3 && RES == 2 && (f & 1)) continue;
+                    const SplitB zs = split_b(mfma_split(split_a(xq[f]), ak[k], f32x4{0.f, 0.f, 0.f, 0.f}));
+#pragma unroll
+                    for (int ct = 0; ct < COT; ++ct) {
+                        if (k < 3) acc[f][ct] = mfma_split(w[ct], zs, acc[f][ct]);
+                        else if constexpr (RES != 0) {
+                            constexpr int sh = RES == 2 ? 1 : 0;
+                            accr[f >> sh][ct] = mfma_split(w[ct], zs, accr[f >> sh][ct]);
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int ct = 0; ct < COT; ++ct) {
+#pragma unroll
+            for (int f = 0; f < FR; ++f)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    stg[(4 * q + r) * (FR * 16) + f * 16 + l16] = acc[f][ct][r] + bias[(16 * ct + 4 * q + r) * 16 + l16];
+            flush(p.y + (size_t)n * p.Co * p.T * 16, TS, co0 + 16 * ct, t0, nf);
+        }
+        if constexpr (RES != 0) {
+            constexpr int st = RES;
+#pragma unroll
+            for (int ct = 0; ct < COT; ++ct) {
+#pragma unroll
+                for (int f = 0; f < FRR; ++f)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        stg[(4 * q + r) * (FR * 16) + f * 16 + l16] = accr[f][ct][r] + bias[16 * COT * 16 + 16 * ct + 4 * q + r];
+                flush(p.res_out + (size_t)n * p.Co * p.To * 16, TOS, co0 + 16 * ct, t0 / st, (nf + st - 1) / st);
+            }
+        }
+        if (++tg == gps) { tg = 0; ++n; }
+    }
+}
+
 // output-channel group of a wide launch: the largest of 128 / 64 / 32 that divides Co and whose W slice fits LDS
 int gcn16_cog(int Ci, int Co, bool res) {
     const int np = res ? 4 : 3;
@@ -765,6 +944,40 @@ int launch_gcn16(const GcnParams& p, hipStream_t st) {
     if (cog == 128) return go(gcn_fwd16_kernel<8>);
     if (cog == 64) return go(gcn_fwd16_kernel<4>);
     return go(gcn_fwd16_kernel<2>);
+}
+
+// split-operand launch: output-channel groups of 64 (or 32): 4-frame accumulators for wider groups do not fit
+int launch_gcn16s(const GcnParams& p, hipStream_t st) {
+    const int np = p.res_w ? 4 : 3;
+    int cog = 0;
+    for (int c = 64; c >= 32; c >>= 1)
+        if (p.Co % c == 0 && (size_t)np * p.Ci * c * 4 + 40 * 1024 <= 160 * 1024) { cog = c; break; }
+    if (cog == 64 && p.res_w && p.stride == 1) cog = 32;      // 4 frames x (4 + 4) accumulator tiles do not fit
+    if (!cog) {
+        step::set_error("step_gcn_fwd_split: no kernel for Ci=%d Co=%d", p.Ci, p.Co);
+        return STEP_ERR_ARG;
+    }
+    const size_t lds = (size_t)np * p.Ci * cog * 4 + (8 * 16 * 4 * 16 + cog * 17) * sizeof(float);
+    const long long units = (long long)p.N * ((p.T + 3) / 4);
+    long long b = (units + 7) / 8;
+    const int groups = p.Co / cog;
+    const long long cap = 256 / groups > 0 ? 256 / groups : 1;
+    b = b < 1 ? 1 : (b > cap ? cap : b);
+    auto go = [&](auto kern) {
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) {
+                step::set_error("step_gcn_fwd_split: hipFuncSetAttribute(%zu): %s", lds, hipGetErrorString(e));
+                return (int)STEP_ERR_LAUNCH;
+            }
+        }
+        hipLaunchKernelGGL(kern, dim3((unsigned)b, groups), dim3(512), lds, st, p);
+        return step::check_launch("step_gcn_fwd_split");
+    };
+    const int res = p.res_w ? p.stride : 0;
+    if (cog == 64) return res == 0 ? go(gcn_fwd16s_kernel<4, 0>) : go(gcn_fwd16s_kernel<4, 2>);
+    return res == 0 ? go(gcn_fwd16s_kernel<2, 0>) : res == 1 ? go(gcn_fwd16s_kernel<2, 1>) : go(gcn_fwd16s_kernel<2, 2>);
 }
 
 // First block (Ci <= 4: the coordinate channels, data_bn folded into the load; Co = 32 | 64; residual 1x1 conv):
@@ -945,11 +1158,11 @@ int launch_gcn_small(const GcnParams& p, hipStream_t st) {
 
 }  // namespace
 
-extern "C" int step_gcn_fwd(const float* x, const float* in_scale, const float* in_shift,
-                            const float* w, const float* b, int w_transposed, const float* A_eff,
-                            int a_nnz_max, float* y, const float* res_w, const float* res_b,
-                            int res_transposed, float* res_out, int N, int Ci, int Co, int K, int T,
-                            int stride, void* stream) {
+namespace {
+int gcn_fwd(const float* x, const float* in_scale, const float* in_shift, const float* w, const float* b,
+            int w_transposed, const float* A_eff, int a_nnz_max, float* y, const float* res_w, const float* res_b,
+            int res_transposed, float* res_out, int N, int Ci, int Co, int K, int T, int stride, bool split,
+            void* stream) {
     STEP_REQUIRE(x && w && A_eff && y, "step_gcn_fwd: null pointer");
     STEP_REQUIRE(N > 0 && Ci > 0 && Co > 0 && T > 0, "step_gcn_fwd: bad shape N=%d Ci=%d Co=%d T=%d", N,
                  Ci, Co, T);
@@ -974,6 +1187,8 @@ extern "C" int step_gcn_fwd(const float* x, const float* in_scale, const float* 
     STEP_REQUIRE(nt <= 0x7fffffffLL, "step_gcn_fwd: too many tiles");
     p.ntiles = (int)nt;
     hipStream_t st = (hipStream_t)stream;
+    // split-operand mode: every layer the frame-per-wave form covers; the first block (HBM-bound) stays as it is
+    if (split && !in_scale && Ci % 16 == 0 && Co % 32 == 0 && Ci <= 256 && Co <= 256) return launch_gcn16s(p, st);
     if (wide) return launch_gcn16(p, st);
     if (Ci <= 4 && (Co == 32 || Co == 64) && !getenv("STEP_GCN_FWD_V1"))
         return Co == 32 ? launch_gcn_small<2>(p, st) : launch_gcn_small<4>(p, st);
@@ -984,4 +1199,23 @@ extern "C" int step_gcn_fwd(const float* x, const float* in_scale, const float* 
     }
     if (a_nnz_max <= 4) return mt == 1 ? launch_gcn<4, 1>(p, st) : launch_gcn<4, 2>(p, st);
     return mt == 1 ? launch_gcn<16, 1>(p, st) : launch_gcn<16, 2>(p, st);
+}
+}  // namespace
+
+extern "C" int step_gcn_fwd(const float* x, const float* in_scale, const float* in_shift,
+                            const float* w, const float* b, int w_transposed, const float* A_eff,
+                            int a_nnz_max, float* y, const float* res_w, const float* res_b,
+                            int res_transposed, float* res_out, int N, int Ci, int Co, int K, int T,
+                            int stride, void* stream) {
+    return gcn_fwd(x, in_scale, in_shift, w, b, w_transposed, A_eff, a_nnz_max, y, res_w, res_b, res_transposed,
+                   res_out, N, Ci, Co, K, T, stride, false, stream);
+}
+
+extern "C" int step_gcn_fwd_split(const float* x, const float* in_scale, const float* in_shift,
+                                  const float* w, const float* b, int w_transposed, const float* A_eff,
+                                  int a_nnz_max, float* y, const float* res_w, const float* res_b,
+                                  int res_transposed, float* res_out, int N, int Ci, int Co, int K, int T,
+                                  int stride, void* stream) {
+    return gcn_fwd(x, in_scale, in_shift, w, b, w_transposed, A_eff, a_nnz_max, y, res_w, res_b, res_transposed,
+                   res_out, N, Ci, Co, K, T, stride, true, stream);
 }

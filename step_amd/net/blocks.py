@@ -82,7 +82,8 @@ class _StBlock(nn.Module):
         bnr = self.residual[1] if self._res_kind == "conv" else None
         spec = BlockSpec(ci, co, kt, stride, self._res_kind, self.transposed, self.a_nnz_max,
                          self.tcn[0], self.tcn[3], bnr, data_bn,
-                         bf16={"bf16": True, "f32_split": "split", "f32_split_wgrad": "split_wgrad"}.get(self.mfma_dtype, False))
+                         bf16={"bf16": True, "f32_split": "split", "f32_split_wgrad": "split_wgrad",
+                               "f32_split_gcn": "split_gcn"}.get(self.mfma_dtype, False))
         g = self.graph_conv.conv
         params = []
         if data_bn is not None:

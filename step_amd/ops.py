@@ -226,8 +226,8 @@ class BlockSpec:
         # bf16 MFMA operands for the temporal conv where those kernels exist (fp32 otherwise)
         # bf16 == "split": fp32 operands as bf16 hi + lo on the bf16 matrix cores (step_tcn_conv_split,
         # step_tcn_wgrad_split); "split_wgrad": only the weight gradient that way, the two convs on fp32 MFMAs
-        split = bf16 in ("split", "split_wgrad")
-        conv_bf = bf16 if bf16 in (True, "split") else False
+        split = bf16 in ("split", "split_wgrad", "split_gcn")
+        conv_bf = True if bf16 is True else ("split" if bf16 in ("split", "split_gcn") else False)
         tr_ok = (not transposed) or split       # st_gctn (ConvTranspose2d) blocks: split modes only
         m0, m2 = (1, 3) if transposed else (0, 2)
         self.bf16_fwd = bool(conv_bf) and tr_ok and tcn_bf16_supported(Co, Co, Kt, stride, m0)
@@ -237,6 +237,8 @@ class BlockSpec:
             self.bf16_fwd = "split" if self.bf16_fwd else False
             self.bf16_dgrad = "split" if self.bf16_dgrad else False
             self.bf16_wgrad = "split" if self.bf16_wgrad else False
+        # "split_gcn": "split" plus the graph-conv forward that way (step_gcn_fwd_split; the first block stays fp32)
+        self.gcn_fwd = "step_gcn_fwd_split" if bf16 == "split_gcn" else "step_gcn_fwd"
         self.residual = residual            # 'none' | 'identity' | 'conv'
         self.transposed = transposed
         self.nnz = nnz
@@ -292,7 +294,7 @@ class StGcnBlockFn(torch.autograd.Function):
 
         y = torch.empty((N, Co, T, 16), dtype=torch.float32, device=dev)
         r = torch.empty((N, Co, To, 16), dtype=torch.float32, device=dev) if res_w is not None else None
-        _lib.call("step_gcn_fwd", x, s0, h0, gcn_w, gcn_b, int(s.transposed), A_eff, s.nnz, y,
+        _lib.call(s.gcn_fwd, x, s0, h0, gcn_w, gcn_b, int(s.transposed), A_eff, s.nnz, y,
                   res_w, res_b, int(s.transposed), r, N, Ci, Co, K, T, st)
 
         m1, i1, s1, h1 = bn_prepare(y, 0, s.bn1, training)

@@ -290,6 +290,49 @@ def test_first_block_forms_agree(Ci, Co, T, N, stride, K, monkeypatch):
         assert_close(a, o.cpu(), 2e-5, name)
 
 
+@pytest.mark.parametrize("Ci,Co,T,N,stride,res,tr,K", [
+    (64, 64, 75, 9, 1, False, False, 3),      # block 2 of the classifier (identity residual: no residual conv here)
+    (32, 64, 75, 5, 2, True, False, 3),       # block 1: residual conv at stride 2, odd T
+    (32, 64, 10, 3, 1, True, False, 3),       # residual conv at stride 1 (narrower channel group)
+    (64, 32, 7, 4, 1, True, True, 3),         # st_gctn (w as (Ci, K Co)), T % 4 != 0
+    (16, 32, 1, 6, 1, False, False, 2),       # one frame, K = 2
+    (128, 256, 6, 2, 2, True, False, 3),      # wide: four channel groups
+    (64, 96, 5, 2, 1, False, False, 1),       # Co % 64 != 0
+])
+def test_gcn_fwd_split_operands_vs_oracle(Ci, Co, T, N, stride, res, tr, K):
+    """step_gcn_fwd_split (x, A, w and the aggregated z as bf16 hi + lo on the bf16 matrix cores) holds the fp32
+    bar against the oracle (tgcn.py:58-67 / :121-130 and the residual conv classifier.py:175-179), through the C-ABI"""
+    from step_amd import _lib
+    d = dev()
+    g = torch.Generator().manual_seed(21)
+    A = (A_spatial(True)[:K] * (torch.rand(K, 16, 16, generator=g) + 0.5)).contiguous()
+    x = torch.randn(N, Ci, T, 16, generator=g)
+    w = torch.randn(K * Co, Ci, 1, 1, generator=g) / Ci ** 0.5
+    b = torch.randn(K * Co, generator=g)
+    wt = w.view(K * Co, Ci).t().contiguous().view(Ci, K * Co, 1, 1) if tr else w
+    ref = stgcn.conv_temporal_graphical(x, A, wt, b, tr)
+    rw = rb = ref_r = r = None
+    To = (T - 1) // stride + 1
+    if res:
+        rw, rb = torch.randn(Co, Ci, generator=g) / Ci ** 0.5, torch.randn(Co, generator=g)
+        ref_r = F.conv2d(x, rw.view(Co, Ci, 1, 1), rb, stride=(stride, 1))
+        r = torch.full((N, Co, To, 16), float("nan"), device=d)
+    y = torch.full((N, Co, T, 16), float("nan"), device=d)
+    rwd = None if rw is None else (rw.t().contiguous() if tr else rw).to(d)
+    _lib.call("step_gcn_fwd_split", x.to(d), None, None, wt.to(d), b.to(d), int(tr), A.to(d), 16, y,
+              rwd, None if rb is None else rb.to(d), int(tr), r, N, Ci, Co, K, T, stride)
+    assert_close(y, ref, TOL, "y")
+    if res:
+        assert_close(r, ref_r, TOL, "res_out")
+    # and it is not the fp32 kernel under another name: the results differ in the last bits
+    y32 = torch.empty_like(y)
+    r32 = None if r is None else torch.empty_like(r)
+    _lib.call("step_gcn_fwd", x.to(d), None, None, wt.to(d), b.to(d), int(tr), A.to(d), 16, y32,
+              rwd, None if rb is None else rb.to(d), int(tr), r32, N, Ci, Co, K, T, stride)
+    assert_close(y, y32.cpu(), 2e-5, "y vs fp32 kernel")
+    assert not torch.equal(y, y32)
+
+
 @pytest.mark.parametrize("C,Kt,T,transposed,res", [(32, 75, 75, True, "identity"), (64, 75, 11, True, "conv"),
                                                     (32, 9, 40, False, None), (64, 75, 240, False, "identity")])
 def test_tcn_const_input(C, Kt, T, transposed, res):

@@ -62,6 +62,9 @@ def main():
         "gcn_fwd": (lambda: _lib.call("step_gcn_fwd", x, None, None, w, b, 0, A, nnz, y, rw, rb, 0, r,
                                       N, Ci, Co, K, T, st),
                     el * (x.numel() + y.numel() + (r.numel() if resconv else 0))),
+        "gcn_fwd_split": (lambda: _lib.call("step_gcn_fwd_split", x, None, None, w, b, 0, A, nnz, y, rw, rb, 0, r,
+                                            N, Ci, Co, K, T, st),
+                          el * (x.numel() + y.numel() + (r.numel() if resconv else 0))),
         "gcn_bwd(all)": (lambda: _lib.call("step_gcn_bwd", dy, dr, x, None, None, w, b, 0, A, nnz, rw, 0, dx, dw,
                                            db, dA, drw, drb, N, Ci, Co, K, T, st, ws, nb),
                          el * (2 * (x.numel() + dy.numel() + (dr.numel() if resconv else 0)) + dx.numel())),
