@@ -353,7 +353,7 @@ def main():
                              "relative), fp32 accumulate; loss, outputs and every gradient of the reference's "
                              "train-step fixtures hold at the fp32 bars"}
         for key, mode in (("wgrad_only", "f32_split_wgrad"), ("all_temporal_kernels", "f32_split"),
-                          ("temporal_and_graph_conv_fwd", "f32_split_gcn")):
+                          ("temporal_and_graph_conv", "f32_split_gcn")):
             step_amd.set_mfma_dtype(model, mode)
             k = min(3, args.steps)
             dts = timed(1, k)

@@ -177,6 +177,20 @@ int step_gcn_bwd_idres(const float* dy, const float* dres, const float* x,
                        float* dx, float* dw, float* db, float* dA, float* dres_w, float* dres_b,
                        int N, int Ci, int Co, int K, int T, int stride,
                        void* ws, size_t ws_bytes, void* stream);
+/* step_gcn_bwd_idres with the MFMA products of the 32 / 64-channel kernels (dz = W^T dy, dA += x^T dz, z = x A,
+ * dW += dy z^T, dWr += dres x^T) on the bf16 matrix cores, every fp32 operand as bf16 hi + lo and the lo * lo term
+ * dropped (the backward half of the opt-in "f32_split_gcn" mode; dx's sum over joints and every reduction stay fp32).
+ * Same arguments, layouts and workspace.  Layers outside Ci, Co in {32, 64} (first block, wide layers) run
+ * step_gcn_bwd_idres's fp32 kernels unchanged.                                                              */
+int step_gcn_bwd_split(const float* dy, const float* dres, const float* x,
+                       const float* in_scale, const float* in_shift,
+                       const float* w, const float* b, int w_transposed,
+                       const float* A_eff, int a_nnz_max,
+                       const float* res_w, int res_transposed,
+                       const float* id_dout, const float* id_out,
+                       float* dx, float* dw, float* db, float* dA, float* dres_w, float* dres_b,
+                       int N, int Ci, int Co, int K, int T, int stride,
+                       void* ws, size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------- temporal convolution ----
  * tcn[2] = Conv2d(C,C,(Kt,1),(s,1),((Kt-1)//2,0)) classifier.py:156-162 and its

@@ -39,6 +39,8 @@ SIGNATURES = {
                          I, I, I, I, I, I, P, Z, P]),
     "step_gcn_bwd_idres": (I, [P, P, P, P, P, P, P, I, P, I, P, I, P, P, P, P, P, P, P, P,
                                I, I, I, I, I, I, P, Z, P]),
+    "step_gcn_bwd_split": (I, [P, P, P, P, P, P, P, I, P, I, P, I, P, P, P, P, P, P, P, P,
+                               I, I, I, I, I, I, P, Z, P]),
     "step_tcn_packed_elems": (Z, [I, I, I, I, I]),
     "step_tcn_pack_weight": (I, [P, P, I, I, I, I, I, P]),
     "step_tcn_conv": (I, [P, P, P, I, P, P, P, P, P, P, P, I, P, I, I, I, I, I, I, I, I, P]),

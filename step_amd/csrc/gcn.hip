@@ -15,6 +15,7 @@
 // by each lane from the x tile in LDS with the <= EMAX non-zeros of column w of A_k held in
 // registers, so A lives entirely on chip.
 #include "common.h"
+#include "split_mfma.h"
 #include <cstdlib>
 #include <type_traits>
 
@@ -734,29 +735,6 @@ __global__ __launch_bounds__(512, 2) void gcn_fwd16_kernel(GcnParams p) {
 // 16x16x4 chain become TWO v_mfma_f32_16x16x32_bf16 on operands split into bf16 hi + lo (any pairing of k works as
 // long as A and B agree).  W lies in LDS already split ([.][lane][COT] x (hi4, lo4), the fp32 image's size); x and
 // the aggregation's result are split in registers once and reused by every partition / output tile.
-typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-// A-role operand: (hi[4], lo[4]) along k; B-role operand: (hi, hi) and (lo, 0).  With K = 32 per instruction
-// (v_mfma_f32_16x16x32_bf16, the full-rate shape; lane (q, .) holds k = 8q .. 8q+7 = the four k-steps x {hi, lo}):
-//   (a_hi, a_lo) . (b_hi, b_hi) = a_hi*b_hi + a_lo*b_hi      (a_hi, a_lo) . (b_lo, 0) = a_hi*b_lo
-struct SplitA { bf16x8_t hl; };
-struct SplitB { bf16x8_t hh, l0; };
-__device__ __forceinline__ SplitA split_a(const f32x4 v) {
-    const bf16x4_t h = __builtin_convertvector(v, bf16x4_t);
-    const bf16x4_t l = __builtin_convertvector(v - __builtin_convertvector(h, f32x4), bf16x4_t);
-    return SplitA{__builtin_shufflevector(h, l, 0, 1, 2, 3, 4, 5, 6, 7)};
-}
-__device__ __forceinline__ SplitB split_b(const f32x4 v) {
-    const bf16x4_t h = __builtin_convertvector(v, bf16x4_t);
-    const bf16x4_t l = __builtin_convertvector(v - __builtin_convertvector(h, f32x4), bf16x4_t);
-    const bf16x4_t z = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
-    return SplitB{__builtin_shufflevector(h, h, 0, 1, 2, 3, 0, 1, 2, 3), __builtin_shufflevector(l, z, 0, 1, 2, 3, 4, 5, 6, 7)};
-}
-__device__ __forceinline__ f32x4 mfma_split(const SplitA& a, const SplitB& b, f32x4 c) {
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.hl, b.l0, c, 0, 0, 0);        // the small term first
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.hl, b.hh, c, 0, 0, 0);
-}
-
 // RES: 0 no residual conv, 1 residual conv at stride 1, 2 at stride 2 (even frames only)
 template <int COT, int RES>
 __global__ __launch_bounds__(512, 1) void gcn_fwd16s_kernel(GcnParams p) {

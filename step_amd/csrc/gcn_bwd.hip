@@ -13,6 +13,7 @@
 // Both kernels are persistent over (n, 8-frame) tiles and keep their reductions in registers;
 // per-block partials are summed in block order by a finalize kernel (bit-reproducible).
 #include "common.h"
+#include "split_mfma.h"
 #include <type_traits>
 
 namespace {
@@ -640,6 +641,12 @@ __global__ __launch_bounds__(256, CIP <= 8 ? 2 : 1) void gcn_bwd_weight_kernel(G
 // 1.9-2.05 GHz while both kernels stream x and dy from HBM.  Staggering / prioritising the SIMD partners changed nothing.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// store target that may be absent: a NULL base gets num_records = 0, so the hardware drops every store (no branch
+// around the stores - see the note on s_waitcnt at gcn_bwd_data16_kernel)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc_opt(const float* base) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, base ? 0x7ffffffc : 0, 0x00020000);
+}
+
 template <int CT>
 __device__ __forceinline__ void lds_frag(const float* p, float (&out)[CT]) {
     if constexpr (CT == 4) {
@@ -669,6 +676,14 @@ __device__ __forceinline__ void fma_ror(float& acc, float c, float src, bool fir
     }
 }
 
+// A note on s_waitcnt here (measured while building the split-operand twin below): vmcnt counts in order, holds 63 at
+// most, and at a control-flow join the compiler waits for the path with the FEWEST newer operations - with the next
+// row's dy and the identity residual's rows requested under `if`s, the dz chain of every other row starts with
+// vmcnt(31 - s), i.e. it waits for loads it has just issued.  Making every request unconditional (IDRES as a template
+// parameter, the last row prefetching itself, stores to a NULL dx dropped through num_records = 0) gives exact waits
+// and changed this kernel by -6 % at 64 -> 64 and +5 % at 32 -> 64 (stride-2 residual): a wash, so this kernel keeps
+// its form.  What bounds both forms is the TCP: 64 bytes per channel row and frame means every request is half a
+// 128-byte line (L2 hit rate 2.7 %, FETCH_SIZE 1.9x the algorithmic bytes, TA busy 81 %); DESIGN section 9.
 template <int CI, int CO, int RES>
 __global__ __launch_bounds__(512, 2) void gcn_bwd_data16_kernel(GbParams p) {
     constexpr int CT = CI / 16;                       // 16-channel tiles of ci
@@ -897,6 +912,231 @@ __global__ __launch_bounds__(512, 2) void gcn_bwd_data16_kernel(GbParams p) {
     }
 }
 
+// Split-operand twin of gcn_bwd_data16_kernel (step_gcn_bwd_split): the two MFMA products on v_mfma_f32_16x16x32_bf16
+// with every fp32 operand as bf16 hi + lo (split_mfma.h).  One instruction pair covers 16 values of the contracted
+// index, lane group q holding 4 of them, so the fragments are regrouped:
+//   dz_k[ci,w]  = SUM_c W_k[c,ci] dy[c,t,w]     A = W (LDS, split once per block: lane (q, ci) holds c = 16 s + 4q + e),
+//                                               B = the lane's four 4-byte loads dy[16 s + 4q + e][t][w], split per row
+//   dA_k[v,w]  += SUM_ci x[ci,t,v] dz_k[ci,w]   A = x[16 j + 4q + e][t][v] (own loads),  B = dz's D registers, rounded
+//                                               to hi + lo here
+// dx (DPP rotations of the fp32 dz), the residual conv term, the identity-residual fusion and the dA reduction are
+// the fp32 kernel's.
+template <int CI, int CO, int RES, bool IDRES>
+__global__ __launch_bounds__(512, 2) void gcn_bwd_data16s_kernel(GbParams p) {
+    constexpr int CT = CI / 16;
+    constexpr int S4 = CO / 16;                       // contraction steps over c (16 output channels each)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    SplitA* Wl = reinterpret_cast<SplitA*>(smem);     // [3][S4][CT][64 lanes]
+    SplitA* Wrl = Wl + 3 * S4 * CT * 64;              // [S4][CT][64]   (RES)
+    float* cfs = reinterpret_cast<float*>(Wrl + (RES ? S4 * CT * 64 : 0));    // [3][16 joints][16 rotations]
+    float* red = smem;                                // [8][768], after the loop
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = lane >> 4, l16 = lane & 15;
+
+    for (int e = tid; e < (3 + (RES ? 1 : 0)) * S4 * CT * 64; e += 512) {
+        const int ln = e & 63, j = (e >> 6) % CT, s = (e / (64 * CT)) % S4, k = e / (64 * CT * S4);
+        const int ci = 16 * j + (ln & 15);
+        f32x4 v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int c = 16 * s + 4 * (ln >> 4) + r;
+            float x = 0.f;
+            if (k < 3) {
+                if (k < p.K) x = p.w_transposed ? p.w[(size_t)ci * (p.K * CO) + k * CO + c] : p.w[((size_t)k * CO + c) * CI + ci];
+            } else {
+                x = p.res_transposed ? p.res_w[(size_t)ci * CO + c] : p.res_w[(size_t)c * CI + ci];
+            }
+            v[r] = x;
+        }
+        Wl[e] = split_a(v);                           // (k == 3 lands in Wrl)
+    }
+    unsigned rmask[3] = {0u, 0u, 0u};
+    static_for<0, 16>([&](auto rt) {
+        constexpr int R = decltype(rt)::value;
+        const int src = __float_as_int(row_ror<R>(__int_as_float(l16)));
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float a = (k < p.K) ? p.A[(k * 16 + l16) * 16 + src] : 0.f;
+            if (tid < 16) cfs[(k * 16 + l16) * 16 + R] = a;
+            if (__ballot(a != 0.f) != 0ull) rmask[k] |= 1u << R;
+        }
+    });
+#pragma unroll
+    for (int k = 0; k < 3; ++k) rmask[k] = __builtin_amdgcn_readfirstlane(rmask[k]);
+    __syncthreads();
+
+    f32x4 dAk[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) dAk[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // this wave's contiguous run of frames.  (Measured: FETCH_SIZE is 1.9x the algorithmic bytes - every 128-byte
+    // line holds two frames of a channel row and the second request comes a whole row-step later, when the L2 has
+    // dropped it.  Giving the two frames of a line to a pair of waves brought that to 1.1x at 32 -> 64 and changed
+    // the time by -2 % / +11 %, so it is not what bounds the kernel; the run per wave stays.)
+    const long long R = (long long)p.N * p.T;
+    const long long nw = (long long)gridDim.x * 8, gw = (long long)blockIdx.x * 8 + wave;
+    const long long r0 = R * gw / nw, r1 = R * (gw + 1) / nw;
+    const int nrows = (int)(r1 - r0);
+    int n = (int)(r0 / p.T), t = (int)(r0 - (long long)n * p.T);
+    const unsigned TS = (unsigned)p.T * 64u, TOS = (unsigned)p.To * 64u;      // bytes per channel row
+    const unsigned lane_x = 4u * q * TS + l16 * 4u, lane_dr = 4u * q * TOS + l16 * 4u;
+
+    // With the MFMA time of a row down to a fraction of an HBM round trip, every operand of row r + 1 is requested
+    // while row r computes: dy / x / dres at its start, the identity residual's two rows after the dA chain (so that
+    // fewer than 63 operations are newer than anything a chain waits for), all unconditionally (the last row
+    // requests itself again) - see the note on s_waitcnt at gcn_bwd_data16_kernel.
+    struct Row { f32x4 dy[S4], x[CT], dr[RES ? S4 : 1], idg[IDRES ? CT : 1], ido[IDRES ? CT : 1]; };
+    auto load_main = [&](int nn, int tt, Row& rw) {
+        const unsigned so = (unsigned)tt * 64u;
+        {
+            const __amdgpu_buffer_rsrc_t rs = make_rsrc(p.dy + (size_t)nn * CO * p.T * 16);
+#pragma unroll
+            for (int s = 0; s < S4; ++s)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) rw.dy[s][e] = bload(rs, lane_x, so + (unsigned)(16 * s + e) * TS);
+        }
+        if constexpr (RES != 0) {
+            if (RES == 1 || (tt & 1) == 0) {          // (stride 2: only even frames have a dres row)
+                const __amdgpu_buffer_rsrc_t rs = make_rsrc(p.dres + (size_t)nn * CO * p.To * 16);
+                const unsigned sr = (unsigned)(RES == 1 ? tt : tt >> 1) * 64u;
+#pragma unroll
+                for (int s = 0; s < S4; ++s)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) rw.dr[s][e] = bload(rs, lane_dr, sr + (unsigned)(16 * s + e) * TOS);
+            }
+        }
+        {
+            const __amdgpu_buffer_rsrc_t rs = make_rsrc(p.x + (size_t)nn * CI * p.T * 16);
+#pragma unroll
+            for (int j = 0; j < CT; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) rw.x[j][e] = bload(rs, lane_x, so + (unsigned)(16 * j + e) * TS);
+        }
+    };
+    auto load_id = [&](int nn, int tt, Row& rw) {
+        if constexpr (IDRES) {
+            const unsigned so = (unsigned)tt * 64u;
+            const __amdgpu_buffer_rsrc_t rg = make_rsrc(p.id_dout + (size_t)nn * CI * p.T * 16);
+            const __amdgpu_buffer_rsrc_t ro = make_rsrc(p.id_out + (size_t)nn * CI * p.T * 16);
+#pragma unroll
+            for (int j = 0; j < CT; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    rw.idg[j][e] = bload(rg, lane_x, so + (unsigned)(16 * j + e) * TS);
+                    rw.ido[j][e] = bload(ro, lane_x, so + (unsigned)(16 * j + e) * TS);
+                }
+        }
+    };
+    auto do_row = [&](int nn, int tt, bool have_next, Row& cur, Row& nxt) {
+        const bool res_row = RES == 1 || (RES == 2 && (tt & 1) == 0);
+        int t2 = tt + 1, n2 = nn;
+        if (t2 == p.T) { t2 = 0; ++n2; }
+        n2 = have_next ? n2 : nn;
+        t2 = have_next ? t2 : tt;
+        load_main(n2, t2, nxt);
+
+        f32x4 dz[3][CT];
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int j = 0; j < CT; ++j) dz[k][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const SplitA* wl = Wl + lane;
+#pragma unroll
+        for (int s = 0; s < S4; ++s) {
+            const SplitB ds = split_b(cur.dy[s]);
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int j = 0; j < CT; ++j) dz[k][j] = mfma_split(wl[((k * S4 + s) * CT + j) * 64], ds, dz[k][j]);
+        }
+        f32x4 dxa[CT];
+#pragma unroll
+        for (int j = 0; j < CT; ++j) dxa[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (RES != 0) {
+            if (res_row) {
+                const SplitA* wr = Wrl + lane;
+#pragma unroll
+                for (int s = 0; s < S4; ++s) {
+                    const SplitB ds = split_b(cur.dr[s]);
+#pragma unroll
+                    for (int j = 0; j < CT; ++j) dxa[j] = mfma_split(wr[(s * CT + j) * 64], ds, dxa[j]);
+                }
+            }
+        }
+        // dA_k += x^T dz_k
+#pragma unroll
+        for (int j = 0; j < CT; ++j) {
+            const SplitA xs = split_a(cur.x[j]);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) dAk[k] = mfma_split(xs, split_b(dz[k][j]), dAk[k]);
+        }
+        __builtin_amdgcn_sched_barrier(0);            // requested HERE, not hoisted to the row's other loads
+        load_id(n2, t2, nxt);
+        __builtin_amdgcn_sched_barrier(0);
+        {                                             // (dx == NULL: computed all the same, stores dropped)
+            float dxr[CT * 4];
+#pragma unroll
+            for (int j = 0; j < CT; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dxr[j * 4 + r] = dxa[j][r];
+            __builtin_amdgcn_sched_barrier(0);
+            static_for<0, 3>([&](auto kt) {
+                constexpr int kq = decltype(kt)::value;
+                static_for<0, 16>([&](auto rt) {
+                    constexpr int RR = decltype(rt)::value;
+                    if ((rmask[kq] >> RR) & 1u) {
+                        const float c = cfs[(kq * 16 + l16) * 16 + RR];       // (one LDS dword per live rotation)
+#pragma unroll
+                        for (int j = 0; j < CT; ++j)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                fma_ror<RR>(dxr[j * 4 + r], c, dz[kq][j][r], j == 0 && r == 0);
+                    }
+                });
+            });
+            if constexpr (IDRES) {
+#pragma unroll
+                for (int i = 0; i < CT * 4; ++i) dxr[i] += cur.ido[i >> 2][i & 3] > 0.f ? cur.idg[i >> 2][i & 3] : 0.f;
+            }
+            // (1 GB of dx costs 0.85 ms of this kernel at N = 4096, 64 -> 64: dword stores, 64 bytes per channel row.
+            // Writing the two frames of each 128-byte line back to back did not change that.)
+            const __amdgpu_buffer_rsrc_t rs = make_rsrc_opt(p.dx ? p.dx + (size_t)nn * CI * p.T * 16 : nullptr);
+            const unsigned so = (unsigned)tt * 64u;
+#pragma unroll
+            for (int i = 0; i < CT * 4; ++i) bstore(rs, lane_x, so + (unsigned)((i >> 2) * 16 + (i & 3)) * TS, dxr[i]);
+        }
+    };
+
+    Row ra, rb;
+    if (nrows > 0) {
+        load_main(n, t, ra);
+        load_id(n, t, ra);
+    }
+    for (int i = 0; i < nrows; i += 2) {
+        do_row(n, t, i + 1 < nrows, ra, rb);
+        if (++t == p.T) { t = 0; ++n; }
+        if (i + 1 < nrows) {
+            do_row(n, t, i + 2 < nrows, rb, ra);
+            if (++t == p.T) { t = 0; ++n; }
+        }
+    }
+
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) red[wave * 768 + (k * 16 + 4 * q + i) * 16 + l16] = dAk[k][i];
+    __syncthreads();
+    for (int e = tid; e < 768; e += 512) {
+        float sum = 0.f;
+#pragma unroll
+        for (int w8 = 0; w8 < 8; ++w8) sum += red[w8 * 768 + e];
+        p.part1[(size_t)blockIdx.x * 768 + e] = sum;
+    }
+}
+
 // Data kernel of the wide layers: a block owns a group of CIG = 16 * CT input channels (blockIdx.y) with the matching
 // slice of W (all Co output channels) in LDS and walks the output channels in chunks of 64, so dz for its group stays
 // in 12 * CT registers whatever Co is.  Otherwise gcn_bwd_data16_kernel: one frame per wave at a time, no barriers.
@@ -1075,7 +1315,9 @@ __global__ __launch_bounds__(512, 2) void gcn_bwd_data16w_kernel(GbParams p) {
 // weight kernel: 512-thread blocks = 8 waves = (CI / 16 input-channel tiles) x (8 / CIT frame streams).  CI / CO are
 // the channels ONE BLOCK covers: wide layers (Ci or Co > 64) run as blockIdx.y = (input group, output group) with the
 // same code, each group writing its own sub-block of the partial row.
-template <int CI, int CO>
+// SPLIT: both products on v_mfma_f32_16x16x32_bf16 with every fp32 operand (A_k, x, z_k, dy, dres) as bf16 hi + lo
+// (split_mfma.h): two instructions where the fp32 form issues four 16x16x4, same fragment layouts.
+template <int CI, int CO, bool SPLIT = false>
 __global__ __launch_bounds__(512, 2) void gcn_bwd_weight16_kernel(GbParams p) {
     constexpr int CIT = CI / 16, COT = CO / 16;
     constexpr int SPB = 8 / CIT;                      // frame streams per block (waves sharing a ci tile)
@@ -1097,6 +1339,11 @@ __global__ __launch_bounds__(512, 2) void gcn_bwd_weight16_kernel(GbParams p) {
     for (int k = 0; k < 3; ++k)
 #pragma unroll
         for (int e = 0; e < 4; ++e) akt[k][e] = (k < p.K) ? p.A[(k * 16 + 4 * q + e) * 16 + l16] : 0.f;
+    SplitA aks[SPLIT ? 3 : 1];
+    if constexpr (SPLIT) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) aks[k] = split_a(f32x4{akt[k][0], akt[k][1], akt[k][2], akt[k][3]});
+    }
 
     f32x4 acc[3][COT], accr[COT];
     f32x4 Sacc[COT], Bacc[COT];
@@ -1138,6 +1385,27 @@ __global__ __launch_bounds__(512, 2) void gcn_bwd_weight16_kernel(GbParams p) {
             int n2 = nn, t2 = tt + 1;
             if (t2 == p.T) { t2 = 0; ++n2; }
             load_row(n2, t2, nxt);
+        }
+        if constexpr (SPLIT) {
+            const SplitB xs = split_b(cur.x);
+            SplitB zs[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) zs[k] = split_b(mfma_split(aks[k], xs, f32x4{0.f, 0.f, 0.f, 0.f}));
+#pragma unroll
+            for (int ct = 0; ct < COT; ++ct) {
+                if (cit == 0 && ci0 == 0) Sacc[ct] += cur.dy[ct];
+                const SplitA ds = split_a(cur.dy[ct]);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) acc[k][ct] = mfma_split(ds, zs[k], acc[k][ct]);
+            }
+            if (have_res && (p.stride == 1 || (tt & 1) == 0)) {
+#pragma unroll
+                for (int ct = 0; ct < COT; ++ct) {
+                    if (cit == 0 && ci0 == 0) Bacc[ct] += cur.dr[ct];
+                    accr[ct] = mfma_split(split_a(cur.dr[ct]), xs, accr[ct]);
+                }
+            }
+            return;
         }
         // z_k = x A_k
         f32x4 z[3];
@@ -1673,29 +1941,33 @@ int gb16_blocks(int N, int T) {
     return (int)(b < 1 ? 1 : (b > 256 ? 256 : b));
 }
 
-template <int CI, int CO>
+template <int CI, int CO, bool SPLIT>
 int launch_gb16(const GbParams& p, int nblk, hipStream_t st) {
     const int res = p.dres ? p.stride : 0;
     size_t lds1 = ((size_t)(3 + (res ? 1 : 0)) * (CO / 4) * 64 * (CI / 16) + 768) * 4;
     if (lds1 < 8 * 768 * 4) lds1 = 8 * 768 * 4;
     constexpr int CIT = CI / 16, COT = CO / 16;
     const size_t lds2 = (size_t)(8 / CIT - 1) * CIT * 64 * (24 * COT) * 4;
-    auto k2 = gcn_bwd_weight16_kernel<CI, CO>;
+    auto k2 = gcn_bwd_weight16_kernel<CI, CO, SPLIT>;
     hipError_t e = hipSuccess;
     auto attr = [&](const void* k, size_t lds) {
         if (e == hipSuccess && lds > 64 * 1024)
             e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     };
     attr(reinterpret_cast<const void*>(k2), lds2);
-    if (res == 0) {
-        attr(reinterpret_cast<const void*>(gcn_bwd_data16_kernel<CI, CO, 0>), lds1);
-        if (e == hipSuccess) hipLaunchKernelGGL((gcn_bwd_data16_kernel<CI, CO, 0>), dim3(nblk), dim3(512), lds1, st, p);
-    } else if (res == 1) {
-        attr(reinterpret_cast<const void*>(gcn_bwd_data16_kernel<CI, CO, 1>), lds1);
-        if (e == hipSuccess) hipLaunchKernelGGL((gcn_bwd_data16_kernel<CI, CO, 1>), dim3(nblk), dim3(512), lds1, st, p);
+    auto data = [&](auto k1) {
+        attr(reinterpret_cast<const void*>(k1), lds1);
+        if (e == hipSuccess) hipLaunchKernelGGL(k1, dim3(nblk), dim3(512), lds1, st, p);
+    };
+    if constexpr (SPLIT) {
+        if (res == 0 && p.id_dout && p.dx) data(gcn_bwd_data16s_kernel<CI, CO, 0, true>);
+        else if (res == 0) data(gcn_bwd_data16s_kernel<CI, CO, 0, false>);
+        else if (res == 1) data(gcn_bwd_data16s_kernel<CI, CO, 1, false>);
+        else data(gcn_bwd_data16s_kernel<CI, CO, 2, false>);
     } else {
-        attr(reinterpret_cast<const void*>(gcn_bwd_data16_kernel<CI, CO, 2>), lds1);
-        if (e == hipSuccess) hipLaunchKernelGGL((gcn_bwd_data16_kernel<CI, CO, 2>), dim3(nblk), dim3(512), lds1, st, p);
+        if (res == 0) data(gcn_bwd_data16_kernel<CI, CO, 0>);
+        else if (res == 1) data(gcn_bwd_data16_kernel<CI, CO, 1>);
+        else data(gcn_bwd_data16_kernel<CI, CO, 2>);
     }
     if (e != hipSuccess) {
         step::set_error("step_gcn_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -1705,9 +1977,10 @@ int launch_gb16(const GbParams& p, int nblk, hipStream_t st) {
     return step::check_launch("step_gcn_bwd");
 }
 
+template <bool SPLIT>
 int dispatch_gb16(const GbParams& p, int nblk, hipStream_t st) {
-    if (p.Ci == 32) return p.Co == 32 ? launch_gb16<32, 32>(p, nblk, st) : launch_gb16<32, 64>(p, nblk, st);
-    return p.Co == 32 ? launch_gb16<64, 32>(p, nblk, st) : launch_gb16<64, 64>(p, nblk, st);
+    if (p.Ci == 32) return p.Co == 32 ? launch_gb16<32, 32, SPLIT>(p, nblk, st) : launch_gb16<32, 64, SPLIT>(p, nblk, st);
+    return p.Co == 32 ? launch_gb16<64, 32, SPLIT>(p, nblk, st) : launch_gb16<64, 64, SPLIT>(p, nblk, st);
 }
 
 template <int CIP, int COPAD, bool RES>
@@ -1784,13 +2057,14 @@ extern "C" int step_gcn_bwd(const float* dy, const float* dres, const float* x, 
                               stride, ws, ws_bytes, stream);
 }
 
-extern "C" int step_gcn_bwd_idres(const float* dy, const float* dres, const float* x, const float* in_scale,
-                                  const float* in_shift, const float* w, const float* b, int w_transposed,
-                                  const float* A_eff, int a_nnz_max, const float* res_w, int res_transposed,
-                                  const float* id_dout, const float* id_out,
-                                  float* dx, float* dw, float* db, float* dA, float* dres_w, float* dres_b,
-                                  int N, int Ci, int Co, int K, int T, int stride, void* ws, size_t ws_bytes,
-                                  void* stream) {
+namespace {
+int gcn_bwd(const float* dy, const float* dres, const float* x, const float* in_scale,
+            const float* in_shift, const float* w, const float* b, int w_transposed,
+            const float* A_eff, int a_nnz_max, const float* res_w, int res_transposed,
+            const float* id_dout, const float* id_out,
+            float* dx, float* dw, float* db, float* dA, float* dres_w, float* dres_b,
+            int N, int Ci, int Co, int K, int T, int stride, void* ws, size_t ws_bytes, bool split,
+            void* stream) {
     STEP_REQUIRE(dy && x && w && A_eff && ws, "step_gcn_bwd: null pointer");
     STEP_REQUIRE((id_dout == nullptr) == (id_out == nullptr), "step_gcn_bwd: id_dout and id_out come together");
     STEP_REQUIRE(!id_dout || (dx && !dres && Ci == Co && stride == 1),
@@ -1858,7 +2132,10 @@ extern "C" int step_gcn_bwd_idres(const float* dy, const float* dres, const floa
         hipLaunchKernelGGL((gcn_bwd_small_kernel<2>), dim3(g.nblk1), dim3(512), 0, st, p);
         rc = step::check_launch("step_gcn_bwd(first block)");
     } else {
-        rc = wide ? launch_gb16w(p, gw, st) : (v2 ? dispatch_gb16(p, g.nblk1, st) : dispatch_gb(p, g, st));
+        // (split operands: the 32 / 64-channel second form only; every other layer runs its fp32 kernels)
+        rc = wide ? launch_gb16w(p, gw, st)
+                  : (v2 ? (split ? dispatch_gb16<true>(p, g.nblk1, st) : dispatch_gb16<false>(p, g.nblk1, st))
+                        : dispatch_gb(p, g, st));
     }
     if (rc) return rc;
     float* tot1 = p.part2 + (size_t)g.nblk2 * g.part2;   // (workspace rows: nblk1_ws + nblk2 + 2)
@@ -1877,4 +2154,27 @@ extern "C" int step_gcn_bwd_idres(const float* dy, const float* dres, const floa
     if (rc == STEP_OK && id_dout && !id_fused)
         rc = step_masked_add(id_dout, id_out, dx, 1, (size_t)N * Ci * T * 16, stream);
     return rc;
+}
+}  // namespace
+
+extern "C" int step_gcn_bwd_idres(const float* dy, const float* dres, const float* x, const float* in_scale,
+                                  const float* in_shift, const float* w, const float* b, int w_transposed,
+                                  const float* A_eff, int a_nnz_max, const float* res_w, int res_transposed,
+                                  const float* id_dout, const float* id_out,
+                                  float* dx, float* dw, float* db, float* dA, float* dres_w, float* dres_b,
+                                  int N, int Ci, int Co, int K, int T, int stride, void* ws, size_t ws_bytes,
+                                  void* stream) {
+    return gcn_bwd(dy, dres, x, in_scale, in_shift, w, b, w_transposed, A_eff, a_nnz_max, res_w, res_transposed,
+                   id_dout, id_out, dx, dw, db, dA, dres_w, dres_b, N, Ci, Co, K, T, stride, ws, ws_bytes, false, stream);
+}
+
+extern "C" int step_gcn_bwd_split(const float* dy, const float* dres, const float* x, const float* in_scale,
+                                  const float* in_shift, const float* w, const float* b, int w_transposed,
+                                  const float* A_eff, int a_nnz_max, const float* res_w, int res_transposed,
+                                  const float* id_dout, const float* id_out,
+                                  float* dx, float* dw, float* db, float* dA, float* dres_w, float* dres_b,
+                                  int N, int Ci, int Co, int K, int T, int stride, void* ws, size_t ws_bytes,
+                                  void* stream) {
+    return gcn_bwd(dy, dres, x, in_scale, in_shift, w, b, w_transposed, A_eff, a_nnz_max, res_w, res_transposed,
+                   id_dout, id_out, dx, dw, db, dA, dres_w, dres_b, N, Ci, Co, K, T, stride, ws, ws_bytes, true, stream);
 }

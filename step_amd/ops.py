@@ -237,8 +237,10 @@ class BlockSpec:
             self.bf16_fwd = "split" if self.bf16_fwd else False
             self.bf16_dgrad = "split" if self.bf16_dgrad else False
             self.bf16_wgrad = "split" if self.bf16_wgrad else False
-        # "split_gcn": "split" plus the graph-conv forward that way (step_gcn_fwd_split; the first block stays fp32)
+        # "split_gcn": "split" plus the graph conv that way (step_gcn_fwd_split / step_gcn_bwd_split; the first block
+        # stays fp32)
         self.gcn_fwd = "step_gcn_fwd_split" if bf16 == "split_gcn" else "step_gcn_fwd"
+        self.gcn_bwd = "step_gcn_bwd_split" if bf16 == "split_gcn" else "step_gcn_bwd_idres"
         self.residual = residual            # 'none' | 'identity' | 'conv'
         self.transposed = transposed
         self.nnz = nnz
@@ -381,7 +383,7 @@ class StGcnBlockFn(torch.autograd.Function):
         nb = _lib.query("step_gcn_bwd_ws_bytes", N, Ci, Co, K, T)
         ws = _ws(nb, dev)
         idres = s.residual == "identity" and dx is not None        # dx += dout * [out > 0], in the same launch
-        _lib.call("step_gcn_bwd_idres", dy, dr, x, s0, h0, gcn_w, gcn_b, int(s.transposed), A_eff, s.nnz,
+        _lib.call(s.gcn_bwd, dy, dr, x, s0, h0, gcn_w, gcn_b, int(s.transposed), A_eff, s.nnz,
                   res_w, int(s.transposed), dout if idres else None, out if idres else None,
                   dx, dgw, dgb, dA, drw, drb, N, Ci, Co, K, T, st, ws, nb)
 

@@ -333,6 +333,69 @@ def test_gcn_fwd_split_operands_vs_oracle(Ci, Co, T, N, stride, res, tr, K):
     assert not torch.equal(y, y32)
 
 
+@pytest.mark.parametrize("Ci,Co,T,N,stride,res,tr,K", [
+    (64, 64, 75, 9, 1, "identity", False, 3),     # block 2 of the classifier
+    (32, 64, 75, 5, 2, "conv", False, 3),         # block 1: residual conv at stride 2, odd T
+    (32, 32, 10, 3, 1, "conv", False, 3),
+    (64, 32, 7, 4, 1, "conv", True, 3),           # st_gctn layouts
+    (32, 32, 1, 6, 1, None, False, 2),            # one frame, K = 2
+    (64, 64, 5, 2, 1, None, False, 1),
+])
+def test_gcn_bwd_split_operands_vs_oracle(Ci, Co, T, N, stride, res, tr, K):
+    """step_gcn_bwd_split (dz = W^T dy, dA += x^T dz, z = x A, dW += dy z^T, dWr += dres x^T on the bf16 matrix cores,
+    operands as bf16 hi + lo) holds the fp32 bar against autograd of the oracle (tgcn.py:58-67 / :121-130, residual conv
+    classifier.py:175-179, identity residual :170-171), through the C-ABI"""
+    from step_amd import _lib
+    d = dev()
+    g = torch.Generator().manual_seed(22)
+    A = (A_spatial(True)[:K] * (torch.rand(K, 16, 16, generator=g) + 0.5)).contiguous()
+    x = torch.randn(N, Ci, T, 16, generator=g)
+    w = torch.randn(K * Co, Ci, 1, 1, generator=g) / Ci ** 0.5
+    b = torch.randn(K * Co, generator=g)
+    wt = w.view(K * Co, Ci).t().contiguous().view(Ci, K * Co, 1, 1) if tr else w
+    To = (T - 1) // stride + 1
+    dy = torch.randn(N, Co, T, 16, generator=g)
+    leaves = [t.clone().requires_grad_(True) for t in (x, A, wt, b)]
+    total = (stgcn.conv_temporal_graphical(*leaves, tr) * dy).sum()
+    rw = rb = dr = dout = out = None
+    if res == "conv":
+        rw, rb = (torch.randn(Co, Ci, generator=g) / Ci ** 0.5).requires_grad_(True), torch.randn(Co, generator=g).requires_grad_(True)
+        dr = torch.randn(N, Co, To, 16, generator=g)
+        total = total + (F.conv2d(leaves[0], rw.view(Co, Ci, 1, 1), rb, stride=(stride, 1)) * dr).sum()
+    total.backward()
+    ref_dx = leaves[0].grad
+    if res == "identity":
+        dout, out = torch.randn(N, Ci, T, 16, generator=g), torch.randn(N, Ci, T, 16, generator=g)
+        ref_dx = ref_dx + dout * (out > 0)
+    nb = _lib.query("step_gcn_bwd_ws_bytes", N, Ci, Co, K, T)
+    ws = torch.empty(nb, dtype=torch.uint8, device=d)
+    dev_ = lambda t: None if t is None else t.detach().to(d)
+    rwd = None if rw is None else (rw.detach().t().contiguous() if tr else rw.detach()).to(d)
+    dx, dw, db, dA = (torch.full(t.shape, float("nan"), device=d) for t in (x, wt, b, A))
+    drw = None if rw is None else torch.full(rwd.shape, float("nan"), device=d)
+    drb = None if rw is None else torch.full((Co,), float("nan"), device=d)
+
+    def run(fn, outs):
+        _lib.call(fn, dev_(dy), dev_(dr), dev_(x), None, None, dev_(wt), dev_(b), int(tr), dev_(A), 16, rwd, int(tr),
+                  dev_(dout), dev_(out), *outs, N, Ci, Co, K, T, stride, ws, nb)
+    run("step_gcn_bwd_split", (dx, dw, db, dA, drw, drb))
+    assert_close(dx, ref_dx, TOL, "dx")
+    assert_close(dw, leaves[2].grad, TOL, "dw")
+    assert_close(db, leaves[3].grad, TOL, "db")
+    supp = (A != 0).float()
+    assert_close(dA.cpu() * supp, leaves[1].grad * supp, TOL, "dA on supp(A)")
+    if rw is not None:
+        assert_close(drw, rw.grad.t() if tr else rw.grad, TOL, "dres_w")
+        assert_close(drb, rb.grad, TOL, "dres_b")
+    # against the fp32 kernels: close, and not the same code under another name
+    f32 = [torch.empty_like(t) for t in (dx, dw, db, dA)] + [None if drw is None else torch.empty_like(drw),
+                                                              None if drb is None else torch.empty_like(drb)]
+    run("step_gcn_bwd_idres", f32)
+    assert_close(dx, f32[0].cpu(), 2e-5, "dx vs fp32 kernel")
+    assert_close(dw, f32[1].cpu(), 2e-5, "dw vs fp32 kernel")
+    assert not torch.equal(dw, f32[1])
+
+
 @pytest.mark.parametrize("C,Kt,T,transposed,res", [(32, 75, 75, True, "identity"), (64, 75, 11, True, "conv"),
                                                     (32, 9, 40, False, None), (64, 75, 240, False, "identity")])
 def test_tcn_const_input(C, Kt, T, transposed, res):

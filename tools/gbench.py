@@ -74,6 +74,12 @@ def main():
         calls["gcn_bwd_idres"] = (lambda: _lib.call("step_gcn_bwd_idres", dy, dr, x, None, None, w, b, 0, A, nnz, rw, 0,
                                                      idg, ido, dx, dw, db, dA, drw, drb, N, Ci, Co, K, T, st, ws, nb),
                                   el * (2 * (x.numel() + dy.numel()) + 3 * dx.numel()))
+    idg_s = torch.randn(N, Ci, T, 16, generator=g).to(d) if (not resconv and Ci == Co) else None
+    ido_s = torch.randn(N, Ci, T, 16, generator=g).to(d) if (not resconv and Ci == Co) else None
+    calls["gcn_bwd_split"] = (lambda: _lib.call("step_gcn_bwd_split", dy, dr, x, None, None, w, b, 0, A, nnz, rw, 0,
+                                                 idg_s, ido_s, dx, dw, db, dA, drw, drb, N, Ci, Co, K, T, st, ws, nb),
+                              el * (2 * (x.numel() + dy.numel() + (dr.numel() if resconv else 0)) + dx.numel()
+                                    + (2 * dx.numel() if idg_s is not None else 0)))
     # BN / elementwise kernels on the block's (N, Co, T, 16) tensor
     bnw, bnb = torch.ones(Co, device=d), torch.zeros(Co, device=d)
     rm, rv = torch.zeros(Co, device=d), torch.ones(Co, device=d)
