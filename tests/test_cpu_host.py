@@ -50,6 +50,17 @@ def test_shape_errors_are_reported_before_launch():
     assert rc == -1 and b"null pointer" in l.step_last_error()
     rc = l.step_gcn_fwd(1, None, None, 1, None, 0, 1, 4, 1, None, None, 0, None, 2, 3, 128, 3, 10, 1, None)
     assert rc == -1 and b"Co=128" in l.step_last_error()          # wide layers need Ci % 16 == 0
+    # the split-operand twins check the same arguments before anything is launched
+    rc = l.step_gcn_fwd_split(1, None, None, 1, None, 0, 1, 4, 1, None, None, 0, None, 2, 32, 64, 4, 10, 1, None)
+    assert rc == -1 and b"K=4" in l.step_last_error()
+    rc = l.step_gcn_fwd_split(1, None, None, 1, None, 0, 1, 4, 1, 1, None, 0, None, 2, 32, 64, 3, 10, 1, None)
+    assert rc == -1 and b"res_w/res_out pair" in l.step_last_error()
+    rc = l.step_gcn_bwd_split(1, None, 1, None, None, 1, None, 0, 1, 4, None, 0, 1, None, 1, None, None, None, None,
+                              None, 2, 64, 64, 3, 10, 1, 1, 0, None)
+    assert rc == -1 and b"id_dout and id_out come together" in l.step_last_error()
+    rc = l.step_gcn_bwd_split(1, None, 1, None, None, 1, None, 0, 1, 4, None, 0, None, None, 1, None, None, None, None,
+                              None, 2, 64, 64, 3, 10, 1, 1, 0, None)
+    assert rc != 0 and b"workspace" in l.step_last_error()
     assert l.step_gcn_bwd_ws_bytes(64, 128, 256, 3, 60) > 0
 
 
