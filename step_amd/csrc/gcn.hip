@@ -931,10 +931,7 @@ int launch_gcn16s(const GcnParams& p, hipStream_t st) {
     for (int c = 64; c >= 32; c >>= 1)
         if (p.Co % c == 0 && (size_t)np * p.Ci * c * 4 + 40 * 1024 <= 160 * 1024) { cog = c; break; }
     if (cog == 64 && p.res_w && p.stride == 1) cog = 32;      // 4 frames x (4 + 4) accumulator tiles do not fit
-    if (!cog) {
-        step::set_error("step_gcn_fwd_split: no kernel for Ci=%d Co=%d", p.Ci, p.Co);
-        return STEP_ERR_ARG;
-    }
+    if (!cog) return -2;                                      // W slice + stage do not fit the LDS: the fp32 kernels take it
     const size_t lds = (size_t)np * p.Ci * cog * 4 + (8 * 16 * 4 * 16 + cog * 17) * sizeof(float);
     const long long units = (long long)p.N * ((p.T + 3) / 4);
     long long b = (units + 7) / 8;
@@ -1166,7 +1163,10 @@ int gcn_fwd(const float* x, const float* in_scale, const float* in_shift, const 
     p.ntiles = (int)nt;
     hipStream_t st = (hipStream_t)stream;
     // split-operand mode: every layer the frame-per-wave form covers; the first block (HBM-bound) stays as it is
-    if (split && !in_scale && Ci % 16 == 0 && Co % 32 == 0 && Ci <= 256 && Co <= 256) return launch_gcn16s(p, st);
+    if (split && !in_scale && Ci % 16 == 0 && Co % 32 == 0 && Ci <= 256 && Co <= 256) {
+        const int rc = launch_gcn16s(p, st);
+        if (rc != -2) return rc;
+    }
     if (wide) return launch_gcn16(p, st);
     if (Ci <= 4 && (Co == 32 || Co == 64) && !getenv("STEP_GCN_FWD_V1"))
         return Co == 32 ? launch_gcn_small<2>(p, st) : launch_gcn_small<4>(p, st);

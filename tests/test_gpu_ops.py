@@ -298,6 +298,7 @@ def test_first_block_forms_agree(Ci, Co, T, N, stride, K, monkeypatch):
     (16, 32, 1, 6, 1, False, False, 2),       # one frame, K = 2
     (128, 256, 6, 2, 2, True, False, 3),      # wide: four channel groups
     (64, 96, 5, 2, 1, False, False, 1),       # Co % 64 != 0
+    (256, 64, 4, 2, 1, True, False, 3),       # W slice + residual conv's do not fit the LDS: the fp32 kernels run
 ])
 def test_gcn_fwd_split_operands_vs_oracle(Ci, Co, T, N, stride, res, tr, K):
     """step_gcn_fwd_split (x, A, w and the aggregated z as bf16 hi + lo on the bf16 matrix cores) holds the fp32
@@ -330,7 +331,7 @@ def test_gcn_fwd_split_operands_vs_oracle(Ci, Co, T, N, stride, res, tr, K):
     _lib.call("step_gcn_fwd", x.to(d), None, None, wt.to(d), b.to(d), int(tr), A.to(d), 16, y32,
               rwd, None if rb is None else rb.to(d), int(tr), r32, N, Ci, Co, K, T, stride)
     assert_close(y, y32.cpu(), 2e-5, "y vs fp32 kernel")
-    assert not torch.equal(y, y32)
+    assert torch.equal(y, y32) == (Ci == 256 and res)
 
 
 @pytest.mark.parametrize("Ci,Co,T,N,stride,res,tr,K", [
