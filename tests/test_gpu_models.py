@@ -243,8 +243,9 @@ def test_full_size_properties():
     assert torch.allclose(full.sum(1).cpu(), torch.ones(512), atol=1e-5)
 
 
-@pytest.mark.parametrize("variant,N", [("real_only", 4096), ("real_and_synth", 512)])
-def test_full_size_train_step_replicated_batch(variant, N):
+@pytest.mark.parametrize("variant,N,mfma", [("real_only", 4096, "f32"), ("real_and_synth", 512, "f32"),
+                                            ("real_only", 4096, "f32_split_gcn")])
+def test_full_size_train_step_replicated_batch(variant, N, mfma):
     """The bench workloads' own shapes in train mode (configs[1]: real_only, N=4096 x 3 x 240 x 16; configs[2]:
     real_and_synth, per-GPU batch 512): a batch made of N/8 copies of 8 gaits has the same batch statistics
     (mean, biased variance), the same mean CrossEntropy and therefore the same parameter gradients as the 8
@@ -259,7 +260,8 @@ def test_full_size_train_step_replicated_batch(variant, N):
     x8 = torch.randn(8, 3, 240, 16, 1, generator=g) * 0.5
     l8 = torch.arange(8) % 4
     loss_ref, out_ref, grads = stgcn.classifier_loss_and_grads({k: v.clone() for k, v in P.items()}, x8, l8, variant)
-    m = _load(_variant_model(variant), P).train()
+    import step_amd
+    m = step_amd.set_mfma_dtype(_load(_variant_model(variant), P).train(), mfma)   # (split operands: same bars)
     x = x8.repeat(N // 8, 1, 1, 1, 1).to(D)
     out, _ = m(x)
     loss = F.cross_entropy(out, l8.repeat(N // 8).to(D))
