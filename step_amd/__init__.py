@@ -17,7 +17,8 @@ def set_mfma_dtype(model, dtype):
     operands rounded to bf16 inside the kernels, fp32 accumulation, fp32 tensors and parameters;
     logits within 1e-2), or "f32_split": fp32 operands split into bf16 hi + lo (16 mantissa bits) and every product
     taken as three bf16 MFMA terms with fp32 accumulation - held to the fp32 bars of the parity tests at about three
-    times the fp32-MFMA kernels' speed ("f32_split_wgrad": only the weight gradient that way).  Blocks without a
+    times the fp32-MFMA kernels' speed ("f32_split_wgrad": only the weight gradient that way; "f32_split_gcn": the
+    graph conv of the 32 / 64-channel blocks too, step_gcn_fwd_split / step_gcn_bwd_split).  Blocks without a
     bf16 kernel (Kt != 75, 3 channels; st_gctn blocks in the "bf16" mode) stay fp32."""
     if dtype not in ("f32", "bf16", "f32_split", "f32_split_wgrad", "f32_split_gcn"):
         raise ValueError("mfma dtype must be 'f32', 'bf16', 'f32_split', 'f32_split_wgrad' or 'f32_split_gcn', got %r" % (dtype,))
