@@ -682,12 +682,13 @@ __device__ __forceinline__ void fma_ror(float& acc, float c, float src, bool fir
 // vmcnt(31 - s), i.e. it waits for loads it has just issued.  Making every request unconditional (IDRES as a template
 // parameter, the last row prefetching itself, stores to a NULL dx dropped through num_records = 0) gives exact waits
 // and changed this kernel by -6 % at 64 -> 64 and +5 % at 32 -> 64 (stride-2 residual): a wash, so this kernel keeps
-// its form.  What bounds both forms is the vector-memory path: a frame is 64 bytes of a channel row, so every operand
-// arrives as 64-lane DWORD instructions (80 per frame with an identity residual; TA busy 81 %, i.e. ~28 cycles each;
-// L2 hit rate 2.7 %, FETCH_SIZE 1.9x the algorithmic bytes).  The split twin's time is linear in their number
-// (0.034 ms per load instruction and frame, 0.066 per store, N = 4096).  Whole-line requests (frame pairs through
-// v_permlane16_swap) were built and measured: -2 % / +10 %, so it is the instruction count, not the request size:
-// the lead is 16-byte accesses through an LDS transpose.
+// its form.  What bounds both forms is NOT settled.  The split twin does a quarter of the MFMA work in the same time
+// (2.64 ms at 64 -> 64, N = 4096; TA busy 81 %, L2 hit rate 2.7 %, FETCH_SIZE 1.9x the algorithmic bytes, waves 43 % of
+// their time in s_waitcnt), and none of these moved it: exact waits, whole-row prefetch, whole-line requests (frame
+// pairs through v_permlane16_swap: -2 % / +10 % on this kernel), 16-byte accesses with an LDS transpose (a quarter of
+// the vector-memory instructions: +2 %), store cache policies.  Removing a tensor does (0.75 ms for the identity
+// residual's two rows, 1.05 ms for dx).  What is left untested is latency inside the wave (every MFMA pair of the
+// twin waits for its own LDS read; two waves per SIMD): DESIGN section 9.
 template <int CI, int CO, int RES>
 __global__ __launch_bounds__(512, 2) void gcn_bwd_data16_kernel(GbParams p) {
     constexpr int CT = CI / 16;                       // 16-channel tiles of ci
