@@ -190,7 +190,27 @@ def cpu_baseline(t, kt=75, n=192):
         stgcn.classifier_loss_and_grads(P, x, y, "real_only")
         dts.append(time.perf_counter() - t0)
     dt = sorted(dts)[1]
+    # the reference's DEFAULT CPU path runs its convolutions through oneDNN; only the forward is usable that way on this
+    # image (oracle/stgcn.py:31-37), so it is timed forward-only (eval), beside the fwd+bwd figure above
+    ne = min(64, n)
+    stgcn.set_onednn(True)
+    try:
+        with torch.no_grad():
+            stgcn.classifier_forward(P, x[:2], "real_only")
+            des = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                stgcn.classifier_forward(P, x[:ne], "real_only")
+                des.append(time.perf_counter() - t0)
+    finally:
+        stgcn.set_onednn(False)
+    de = sorted(des)[1]
+    onednn_eval = {"value": round(ne / de, 3), "unit": "sequences/s", "cores": threads, "kind": "port",
+                   "sample": "oracle eval forward only, oneDNN ENABLED (the reference's default CPU convolution path), "
+                             "N=%d x 3 x %d x 16 fp32, median of 3 passes (%.1f s each); compare with "
+                             "inference_sequences_per_s_per_gpu, not with `value`" % (ne, t, de)}
     return {"value": round(n / dt, 3), "unit": "sequences/s", "cores": threads, "kind": "port",
+            "onednn_eval_forward": onednn_eval,
             "sample": "oracle fwd+bwd (CrossEntropy, no optimizer), N=%d x 3 x %d x 16 fp32, median of 3 passes "
                       "(%.1f s each); torch CPU kernels with oneDNN DISABLED (its conv backward is unusable for "
                       "these (Kt,1) kernels on this image, oracle/stgcn.py:31-37) - the reference's default CPU "

@@ -80,7 +80,9 @@ int step_bn_train_finalize(const double* sums, double count, const float* gamma,
  * stream's).  Limit: G = C (mode 0) or 16*C (mode 1) <= STEP_BN_STATIC_MAX_GROUPS, larger shapes are
  * rejected with STEP_ERR_ARG.  Calls no hipMalloc / hipFree.  Every call on a GPU shares that GPU's array:
  * calls that overlap on one GPU (two streams, two host threads) race - serialise them or use the
- * workspace form.  Nothing in the array has to start at zero.                                          */
+ * workspace form.  Nothing in the array has to start at zero.  Under HIP graph capture: make ONE ordinary
+ * call on the device before capturing (the first call's hipGetSymbolAddress is not a capturable call); every
+ * later call, captured or not, only launches kernels.                                                  */
 #define STEP_BN_STATIC_MAX_GROUPS 256
 int step_bn_train_prepare_static(const float* x, int N, int C, int T, int V, int bn_mode,
                                  const float* gamma, const float* beta,

@@ -287,7 +287,11 @@ __device__ __forceinline__ void ws_body(const WsParams& p, const int lb, char* s
             const float sc = inside ? bsc : 0.f, sh = inside ? bsh : 0.f;
             // two VALU instructions per element (fma, max: ReLU is a lower bound of 0, or -inf without it); every
             // VALU instruction of an MFMA wave adds to its MFMA time (fp32 stride-2 wgrad 38.9 -> 37.5 ms against
-            // the four of fma / max / select on in_relu / select on `inside`)
+            // the four of fma / max / select on in_relu / select on `inside`).  Consequence for in_relu == 0 (no model
+            // path uses it): v_max(NaN, -inf) is -inf, so a NaN activation reaches dw as +-inf / NaN of the products
+            // with -inf instead of as a NaN of its own - dw is non-finite either way
+            // (tests/test_gpu_ops.py::test_wgrad_nan_input_without_relu_stays_non_finite).  Frames outside the
+            // sequence and channels past Ci always land from the zero line, so 0 * x there is 0.
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e] * sc + sh, relu_lo);
         };

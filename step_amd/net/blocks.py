@@ -95,10 +95,10 @@ class _StBlock(nn.Module):
         out = StGcnBlockFn.apply(spec, self.training, x, A, *params)
         return out, A
 
-
     def forward_repeated(self, h, A, T):
         """Eval-mode forward of `x = h[:, :, None, None].repeat(1, 1, T, 16)` without building x
         (the decoder's first block, CVAE_stgcn.py:209-212); no autograd graph is recorded."""
+        self._refuse_child_hooks()
         ci, co, kt, stride = self._geom
         bnr = self.residual[1] if self._res_kind == "conv" else None
         spec = BlockSpec(ci, co, kt, stride, self._res_kind, self.transposed, self.a_nnz_max,

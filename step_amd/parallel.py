@@ -93,6 +93,8 @@ class GradBucket:
             if p.grad is not v:
                 if p.grad is not None:
                     v.copy_(p.grad)
+                else:
+                    v.zero_()               # dropped by zero_grad(set_to_none=True): never a stale averaged gradient
                 p.grad = v
 
     def zero_grad(self):

@@ -186,3 +186,102 @@ def test_hooks_on_block_children_are_refused():
     with pytest.raises(_lib.StepHipError, match="gcn.conv"):
         m.st_gcn_networks[0](torch.zeros(1, 3, 4, 16), m.A)
     h.remove()
+    # the decoder's synthesis fast path (forward_repeated) refuses as well
+    from step_amd.net.CVAE_stgcn import CVAE
+    c = CVAE(3, 75, 16, 32, 4, {"strategy": "spatial"})
+    blk = c.decoder.decoder[0]
+    h = blk.relu.register_forward_hook(lambda mod, i, o: None)
+    with pytest.raises(_lib.StepHipError, match="hook"):
+        blk.forward_repeated(torch.zeros(2, 32), c.decoder.A, 75)
+    h.remove()
+
+
+def test_weights_init_moves_exactly_the_conv2d_and_batchnorm_tensors():
+    """a11: processor.py:117-129 applied through `model.apply` to a step_amd CVAE re-initialises every Conv2d /
+    BatchNorm* weight and bias and NO ConvTranspose2d tensor ('Conv2d' is not a substring of 'ConvTranspose2d'), so the
+    reference harness initialises a step_amd model exactly as it initialises its own."""
+    from step_amd import harness
+    from step_amd.net import CVAE_stgcn
+    torch.manual_seed(11)
+    m = CVAE_stgcn.CVAE(3, 75, 16, 32, 4, {"strategy": "spatial"})
+    with torch.no_grad():
+        for p in m.parameters():
+            p.add_(0.123)                                   # so that "bias filled with 0" is a visible move
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    m.apply(harness.weights_init)
+    after = m.state_dict()
+    expect_moved = set()
+    for name, mod in m.named_modules():
+        cls = type(mod).__name__
+        if cls in ("Conv2d", "BatchNorm1d", "BatchNorm2d"):
+            expect_moved |= {name + ".weight", name + ".bias"}
+        elif cls == "ConvTranspose2d":
+            assert torch.equal(after[name + ".weight"], before[name + ".weight"]), name
+    moved = {k for k in after if not torch.equal(after[k], before[k])}
+    assert moved == expect_moved and len(moved) > 40
+    assert any(".gctn.conv" in k or "decoder.fcn" in k for k in set(after) - moved)
+    for k in moved:
+        if k.endswith(".bias"):
+            assert float(after[k].abs().max()) == 0.0, k
+    w = after["encoder.encoder.1.tcn.2.weight"]
+    assert abs(float(w.std()) - 0.02) < 2e-3 and abs(float(w.mean())) < 2e-3
+    g = after["encoder.encoder.1.tcn.0.weight"]
+    assert abs(float(g.mean()) - 1.0) < 2e-2
+
+
+def test_epoch_harness_host_logic(tmp_path):
+    """step_amd.harness: step epochs / adjust_lr (processor.py:238,260-268), top-k (processor.py:294-307), checkpoint
+    naming and look-up (processor.py:142-148,403-406), the synthetic 342-gait split"""
+    from step_amd import harness
+    assert harness.step_epochs(500) == [250, 375, 438]
+    assert harness.step_epochs(4) == [2, 3, 4]
+    steps = harness.step_epochs(8)
+    assert steps == [4, 6, 7]
+    lrs, lr = [], 0.1
+    for e in range(8):
+        lr = harness.lr_at(e, 0.1, steps) or lr
+        lrs.append(round(lr, 7))
+    assert lrs == [0.1, 0.1, 0.1, 0.1, 0.01, 0.01, 0.001, 0.0001]
+    res = np.array([[0.1, 0.7, 0.2], [0.5, 0.3, 0.2], [0.2, 0.3, 0.5], [0.6, 0.3, 0.1]])
+    assert harness.topk_accuracy(res, [1, 1, 2, 2], 1) == 50.0
+    assert harness.topk_accuracy(res, [1, 1, 2, 2], 2) == 75.0
+    for name in ("epoch3_acc62.50_model.pth.tar", "epoch12_acc81.25_model.pth.tar", "log.txt", "epoch1_acc40.62_model.pth.tar"):
+        (tmp_path / name).write_text("x")
+    assert harness.CKPT_FORMAT.format(12, 81.25) == "epoch12_acc81.25_model.pth.tar"
+    e, a, p = harness.best_checkpoint(str(tmp_path))
+    assert (e, a) == (12, 81.25) and p.endswith("epoch12_acc81.25_model.pth.tar")
+    (tr_x, tr_y), (te_x, te_y) = harness.synthetic_gaits(342, 75, 4, seed=1)
+    assert tr_x.shape == (307, 3, 75, 16, 1) and te_x.shape == (35, 3, 75, 16, 1)
+    assert float(tr_x[:, :, :, 0].abs().max()) == 0.0          # root-relative
+    assert set(tr_y.tolist()) == {0, 1, 2, 3} and -1.5 < float(tr_x.min()) and float(tr_x.max()) < 1.5
+
+
+_UNUSED_PARAM_WORKER = r"""
+import sys, torch
+sys.path.insert(0, '__ROOT__')
+from step_amd import parallel
+torch.manual_seed(0)
+a, b = torch.nn.Linear(3, 2), torch.nn.Linear(3, 2)          # b is never used in the second step
+params = list(a.parameters()) + list(b.parameters())
+bucket = parallel.GradBucket(params)
+opt = torch.optim.SGD(params, lr=0.1)
+x = torch.randn(4, 3)
+bucket.zero_grad()
+(a(x).sum() + b(x).sum()).backward()
+assert float(bucket.flat.abs().sum()) > 0
+opt.zero_grad(set_to_none=True)                              # drops every view
+a(x).sum().backward()                                        # b gets no gradient this step
+bucket._attach()
+off = sum(p.numel() for p in a.parameters())
+assert float(bucket.flat[off:].abs().max()) == 0.0, "stale gradient of an unused parameter survived"
+assert all(p.grad is not None for p in params)
+assert float(bucket.flat[:off].abs().sum()) > 0
+print("ok")
+"""
+
+
+def test_grad_bucket_zeroes_slices_dropped_by_set_to_none(tmp_path):
+    script = tmp_path / "w.py"
+    script.write_text(_UNUSED_PARAM_WORKER.replace("__ROOT__", ROOT))
+    out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr

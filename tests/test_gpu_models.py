@@ -533,3 +533,123 @@ def test_eval_under_no_grad_takes_the_fused_epilogue(monkeypatch):
     unfused, _ = m(x)
     assert len(calls) == 3 and unfused.requires_grad
     assert_close(fused, unfused.detach(), 1e-5, "fused vs separate epilogue")
+
+
+def test_full_size_decoder_synthesis_replicated_batch():
+    """BASELINE configs[3] at its stated size (Decoder.forward CVAE_stgcn.py:198-232, micro-batch 2048, T = 75, eval,
+    z = randn * 3 - 1.5 and one-hot classes cycling 0-3 as processor_stgcn.py:311-333): 8 distinct (z, class) rows
+    x 256.  Eval is per-sample, so copies must agree BIT FOR BIT wherever they sit in the batch, rows 0-7 must be the
+    oracle's, and the reference's own decoder fixture rows must come out the same inside the big batch."""
+    from step_amd.net.CVAE_stgcn import CVAE
+    P = ckpt("ckpt_cvae_epoch105")
+    m = CVAE(3, 75, 16, 32, 4, {"strategy": "spatial"})
+    m.load_state_dict(P)
+    m = m.to(D).eval()
+    g = torch.Generator().manual_seed(2048)
+    z8 = torch.randn(8, 32, generator=g) * 3 - 1.5
+    l8 = F.one_hot(torch.arange(8) % 4, 4).float()
+    N = 2048
+    with torch.no_grad():
+        out = m.decoder(z8.repeat(N // 8, 1).to(D), l8.repeat(N // 8, 1).to(D), 75, 16)
+        ref = stgcn.decoder_forward({k: v.clone() for k, v in P.items()}, z8, l8, 75, 16)
+    assert tuple(out.shape) == (N, 3, 75, 16, 1)
+    assert_close(out[:8], ref, 1e-4, "decoder rows vs oracle")
+    blocks = out.view(N // 8, 8, 3, 75, 16, 1)
+    assert torch.equal(blocks, blocks[:1].expand_as(blocks)), "copies of a (z, class) row differ inside the batch"
+    # the reference's own fixture rows inside a full micro-batch (positions 0.. and N-4..)
+    d = sub(load_npz("cvae_eval"), "")
+    k = d["z"].shape[0]
+    zz = torch.cat((d["z"], z8.repeat((N - 2 * k) // 8 + 1, 1)[:N - 2 * k], d["z"]))
+    ll = torch.cat((d["onehot"], l8.repeat((N - 2 * k) // 8 + 1, 1)[:N - 2 * k], d["onehot"]))
+    with torch.no_grad():
+        big = m.decoder(zz.to(D), ll.to(D), 75, 16)
+    assert_close(big[:k], d["dec75"], 1e-4, "reference fixture rows at the head of a 2048 batch")
+    assert torch.equal(big[:k], big[N - k:])
+
+
+def test_full_size_hybrid_eval_f27_replicated_batch():
+    """BASELINE configs[4] at its stated size and with the reference's DEFAULT feature count
+    (classifier_hybrid/net/classifier.py:61-89; F = 27 = len(data_train[0][0]) of classifier_hybrid/main.py:62 without
+    the stride features): N = 1024, T = 1024, eval.  8 distinct (gait, affective vector) pairs x 128 against the
+    oracle on the 8 (the oracle is pinned to the reference at F = 29 by hybrid_eval_T1024.npz; the best hybrid
+    checkpoint is missing, so the head is seeded random), copies bit-equal, batch-split invariance at that size."""
+    from step_amd.net import classifier_hybrid
+    base = ckpt("ckpt_classifier_real_only_epoch395")
+    torch.manual_seed(27)
+    m = classifier_hybrid.Classifier(3, 27, 4, {"strategy": "spatial"})
+    sd = m.state_dict()
+    for k, v in base.items():
+        k2 = k.replace("data_bn.", "data_bn1.")
+        if k2 in sd and not k.startswith("fcn."):
+            sd[k2] = v.clone()
+    g = torch.Generator().manual_seed(1024)
+    sd["data_bn2.running_mean"] = torch.randn(91, generator=g) * 0.1
+    sd["data_bn2.running_var"] = torch.rand(91, generator=g) + 0.5
+    sd["data_bn2.weight"] = torch.rand(91, generator=g) + 0.5
+    sd["data_bn2.bias"] = torch.randn(91, generator=g) * 0.1
+    m.load_state_dict(sd)
+    P = {k: v.clone() for k, v in m.state_dict().items()}
+    m = m.to(D).eval()
+    x8 = torch.randn(8, 3, 1024, 16, 1, generator=g) * 0.5
+    a8 = torch.rand(8, 27, generator=g) * 2 - 1
+    N = 1024
+    with torch.no_grad():
+        ref = stgcn.classifier_forward(P, x8, "hybrid", x_aff=a8)
+        xg, ag = x8.repeat(N // 8, 1, 1, 1, 1).to(D), a8.repeat(N // 8, 1).to(D)
+        out = m(ag, xg)
+        assert tuple(out.shape) == (N, 4)
+        assert_close(out[:8], ref, 1e-4, "hybrid logits, F = 27, T = 1024")
+        assert torch.equal(out.view(N // 8, 8, 4), out[:8].expand(N // 8, 8, 4))
+        parts = torch.cat([m(ag[i:i + 344], xg[i:i + 344]) for i in range(0, N, 344)])
+    assert torch.equal(out, parts)
+
+
+def test_epoch_level_caller_train_save_reload_eval(tmp_path):
+    """BASELINE configs[0] through the HIP modules: processor.py:260-268 (adjust_lr), :309-344 (per_train), :346-379
+    (per_test, top-1), :381-406 (train, checkpoint naming), :447-455 (load_best_model) as step_amd.harness.EpochRunner
+    on 342 synthetic gaits at T = 75, batch 8, drop_last, Adam(0.1, 1e-4), 4 epochs."""
+    import os
+    import re
+    from step_amd import harness
+    from step_amd.net.classifier import Classifier
+    torch.manual_seed(0)
+    train_set, test_set = harness.synthetic_gaits(342, 75, 4, seed=0)
+    assert train_set[0].shape == (307, 3, 75, 16, 1) and test_set[0].shape == (35, 3, 75, 16, 1)
+    run = harness.EpochRunner(Classifier(3, 4, {"strategy": "spatial"}), train_set, test_set, str(tmp_path), 4,
+                              device=D, seed=0)
+    assert run.steps == [2, 3, 4]
+    hist = run.train()
+    assert len(hist) == 4 and run.meta["iter"] == 4 * 38                    # 307 // 8 batches per epoch
+    assert [round(h["lr"], 6) for h in hist] == [0.1, 0.1, 0.01, 0.001]     # ceil(4 * [0.5, 0.75, 0.875]) = 2, 3, 4
+    losses = [h["train_loss"] for h in hist]
+    assert all(l == l and l < 10 for l in losses) and losses[-1] < losses[0], losses
+    for name, mod in run.model.named_modules():
+        if isinstance(mod, torch.nn.modules.batchnorm._BatchNorm):
+            assert int(mod.num_batches_tracked) == run.meta["iter"], name
+    saved = [h["saved"] for h in hist if "saved" in h]
+    assert saved and all(re.fullmatch(r"epoch\d+_acc\d+\.\d\d_model\.pth\.tar", os.path.basename(p)) for p in saved)
+    assert os.path.basename(saved[-1]) == harness.CKPT_FORMAT.format(run.best_epoch, run.best_accuracy.item())
+    # the model as it was when the best checkpoint was written: reload by file-name parsing in a FRESH runner
+    best_epoch, best_acc = run.best_epoch, run.best_accuracy.item()
+    fresh = harness.EpochRunner(Classifier(3, 4, {"strategy": "spatial"}), train_set, test_set, str(tmp_path), 4,
+                                device=D, seed=0)
+    path = fresh.load_best_model()
+    assert path == saved[-1] and fresh.best_epoch == best_epoch
+    sd_file = torch.load(path, map_location=D, weights_only=True)
+    for k, v in fresh.model.state_dict().items():
+        assert torch.equal(v, sd_file[k]), k
+    # evaluation of the reloaded model reproduces the saved accuracy (same 32 of the 35 test gaits: drop_last with a
+    # shuffled order, so compare on the full, unshuffled test set in one batch instead of the loader's sample)
+    fresh.model.eval()
+    with torch.no_grad():
+        a, _ = fresh.model(fresh.test_set[0])
+        b, _ = fresh.model(fresh.test_set[0])
+        one, _ = fresh.model(fresh.test_set[0][:5])
+    assert torch.equal(a, b) and torch.equal(a[:5], one)                    # bit-for-bit logits after the reload
+    _, accs = fresh.per_test()
+    assert 0.0 <= accs[1] <= 100.0
+    if best_epoch == len(hist) - 1:                                         # best == last: the live model IS the file
+        run.model.eval()
+        with torch.no_grad():
+            live, _ = run.model(run.test_set[0])
+        assert torch.equal(live, a)

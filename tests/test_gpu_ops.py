@@ -544,3 +544,23 @@ def test_tcn_split_operands_forward_dgrad_vs_oracle(C, stride, T, N):
                       N, C, C, T, To, Kt, stride, 2, bf16="split")
     assert_close(da, a.grad, TOL, "split dgrad")
     assert relerr(da, a.grad) < 2e-5
+
+
+@pytest.mark.parametrize("bf16", [False, "split"])
+def test_wgrad_nan_input_without_relu_stays_non_finite(bf16):
+    """tcn_wgrad_sw.hip applies the activation as max(x * scale + shift, lo) with lo = -inf when in_relu == 0, and
+    v_max(NaN, -inf) is -inf: a NaN in the input of a no-ReLU weight gradient must still leave dw non-finite (no
+    model path calls the kernel that way; the reference's conv backward would give NaN there)."""
+    from step_amd import ops
+    d = dev()
+    g = torch.Generator().manual_seed(21)
+    N, C, T = 2, 64, 20
+    y = torch.randn(N, C, T, 16, generator=g)
+    y[1, 5, 7, 3] = float("nan")
+    du = torch.randn(N, C, T, 16, generator=g)
+    sc, sh = torch.ones(C), torch.zeros(C)
+    dw, db = ops.tcn_wgrad(du.to(d), y.to(d), sc.to(d), sh.to(d), False, N, C, C, T, T, 75, 1, False, (C, C, 75, 1),
+                           bf16=bf16)
+    assert not bool(torch.isfinite(dw[:, 5]).all()), "a NaN activation vanished from the weight gradient"
+    others = torch.cat((dw[:, :5], dw[:, 6:]), dim=1)
+    assert bool(torch.isfinite(others).all()) and bool(torch.isfinite(db).all())
