@@ -153,6 +153,21 @@ int step_gcn_fwd_split(const float* x, const float* in_scale, const float* in_sh
                        const float* res_w, const float* res_b, int res_transposed, float* res_out,
                        int N, int Ci, int Co, int K, int T, int stride, void* stream);
 
+/* step_gcn_fwd for a TRAIN-mode block: also returns the batch statistics the BatchNorms behind the two outputs need
+ * (tcn[0] on y, residual[1] on res_out: nn.BatchNorm2d in classifier.py:154,180) as y_sums / r_sums = [SUM, SUM of
+ * squares] per output channel over (N, T, V), 2*Co doubles each, in the layout step_bn_train_finalize takes
+ * (r_sums NULL iff res_w is NULL).  For Ci, Co in {32, 64} without data_bn the sums are taken in the kernel's
+ * epilogue (per-wave fp32 over at most 64 frames, then fp64 partials per block, ordered sums: bit-reproducible)
+ * and y / res_out are not read again; every other shape runs step_gcn_fwd followed by step_bn_train_stats.
+ * ws: step_gcn_fwd_stats_ws_bytes(Co) bytes.                                                              */
+size_t step_gcn_fwd_stats_ws_bytes(int Co);
+int step_gcn_fwd_stats(const float* x, const float* in_scale, const float* in_shift,
+                       const float* w, const float* b, int w_transposed,
+                       const float* A_eff, int a_nnz_max, float* y,
+                       const float* res_w, const float* res_b, int res_transposed, float* res_out,
+                       int N, int Ci, int Co, int K, int T, int stride,
+                       double* y_sums, double* r_sums, void* ws, size_t ws_bytes, void* stream);
+
 /* backward of the above (K16 of SURVEY 2.2).  Any of dx, dw/db, dA, dres_w/dres_b may be
  * NULL.  dA is returned on the support of A_eff only (d importance = A * dA needs no more).
  * ws: step_gcn_bwd_ws_bytes(...) bytes.                                                    */

@@ -34,6 +34,8 @@ SIGNATURES = {
     "step_masked_add": (I, [P, P, P, I, Z, P]),
     "step_gcn_fwd": (I, [P, P, P, P, P, I, P, I, P, P, P, I, P, I, I, I, I, I, I, P]),
     "step_gcn_fwd_split": (I, [P, P, P, P, P, I, P, I, P, P, P, I, P, I, I, I, I, I, I, P]),
+    "step_gcn_fwd_stats_ws_bytes": (Z, [I]),
+    "step_gcn_fwd_stats": (I, [P, P, P, P, P, I, P, I, P, P, P, I, P, I, I, I, I, I, I, P, P, P, Z, P]),
     "step_gcn_bwd_ws_bytes": (Z, [I, I, I, I, I]),
     "step_gcn_bwd": (I, [P, P, P, P, P, P, P, I, P, I, P, I, P, P, P, P, P, P,
                          I, I, I, I, I, I, P, Z, P]),

@@ -377,6 +377,13 @@ size_t ws_bytes(int G) { return ((size_t)BN_MAX_CHUNKS * G * 2 + 2 * (size_t)G) 
 
 extern "C" size_t step_bn_ws_bytes(int G) { return G > 0 ? ws_bytes(G) : 0; }
 
+// ordered sum of per-block fp64 partials [nchunks][G][2] (written by a producer kernel's epilogue, gcn.hip) into
+// sums [G][2]: the second stage of step_bn_train_stats for statistics taken where the tensor is produced
+int step::bn_sum_partials(const double* part, double* sums, int G, int nchunks, hipStream_t st) {
+    hipLaunchKernelGGL(bn_sum_chunks_kernel, dim3(step::ceil_div(2 * G, 64)), dim3(256), 0, st, part, sums, G, nchunks);
+    return step::check_launch("bn_sum_partials");
+}
+
 extern "C" int step_bn_eval_prepare(const float* gamma, const float* beta, const float* running_mean,
                                     const float* running_var, float eps, float* scale, float* shift,
                                     int G, void* stream) {

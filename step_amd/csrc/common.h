@@ -31,6 +31,9 @@ int wgrad_sw(const float* dout, const float* in, const float* in_scale, const fl
              float* dw, float* db, int N, int Ci, int Co, int Tin, int Tout, int Kt, int stride,
              int transposed, void* ws, size_t ws_bytes, hipStream_t st, int bf16 = 0);
 
+// bn.hip: ordered sum of producer-epilogue statistic partials [nchunks][G][2] -> sums [G][2]
+int bn_sum_partials(const double* part, double* sums, int G, int nchunks, hipStream_t st);
+
 }  // namespace step
 
 // raw buffer access: descriptor (uniform base) + 32-bit lane offset + uniform SGPR offset - no 64-bit VALU address

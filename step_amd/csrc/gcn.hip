@@ -34,6 +34,8 @@ struct GcnParams {
     float* res_out;
     int w_transposed, res_transposed;
     int N, Ci, Cip, Co, Copad, K, T, To, stride, tiles_per_seq, ntiles;
+    double* ypart;      // fourth form only: per-block fp64 partials [blocks][Co][2] of SUM y, SUM y^2 (NULL: none)
+    double* rpart;      // ... and of the residual conv's output
 };
 
 constexpr int GCN_TT = 8;             // frames per tile
@@ -887,6 +889,339 @@ __global__ __launch_bounds__(512, 1) void gcn_fwd16s_kernel(GcnParams p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Fourth form (round 3): gcn_fwd16_kernel's products (fp32, v_mfma_f32_16x16x4_f32, one frame = one column tile) in
+// gcn_fwd16s_kernel's work shape: a wave owns FR = 4 consecutive frames of one sequence and ALL output channels of
+// the block's group, so
+//   * the aggregation z_k = x A_k is computed once per (frame, partition, 16 input channels) - the second form
+//     recomputed it per M tile (+50 % MFMA cycles at 32 -> 64);
+//   * a W fragment read (one ds_read_b128 = 4 output tiles) serves 4 frames = 16 MFMAs instead of 4;
+//   * results leave through a wave-private LDS stage as 16-byte pieces of 256-BYTE channel rows: the direct dword
+//     stores of the third form are 64-byte pieces and hold the write path at 2.4 TB/s (3.28 ms at 32 -> 64, N = 4096,
+//     6 of the 8 GB written), staged rows reach ~3.9 TB/s (first block).
+// Optional epilogue (p.ypart != NULL): per-channel SUM y, SUM y^2 (and of the residual conv's output) for the
+// train-mode BatchNorm that follows (tcn[0], residual[1]: classifier.py:154,180) - per-lane fp32 sums over at most
+// STAT_FLUSH work units, then fp64: 16-lane DPP row sums into per-wave LDS accumulators, an ordered sum over the 8
+// waves, one fp64 partial per (block, channel) for bn.hip's ordered finalize.  Bit-reproducible run to run.
+// RES: 0 no residual conv, 1 at stride 1, 2 at stride 2 (even frames).
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row16_sum(float v) {          // every lane of a row of 16 gets the row's sum
+    v += dpp_f<0x128>(v);                                       // row_ror:8
+    v += dpp_f<0x124>(v);                                       // row_ror:4
+    v += dpp_f<0x122>(v);                                       // row_ror:2
+    v += dpp_f<0x121>(v);                                       // row_ror:1
+    return v;
+}
+
+#ifndef F16_STORE_AUX
+#define F16_STORE_AUX 0
+#endif
+constexpr int F16_FR = 4;                 // frames per work unit
+constexpr int F16_ROW = F16_FR * 16 + 4;  // stage row stride in floats: +4 keeps the four q groups on distinct banks
+constexpr int STAT_FLUSH = 16;            // work units between two flushes of the fp32 per-lane sums
+
+template <int CIT, int COT, int RES>
+__global__ __launch_bounds__(512, 1) void gcn_fwd16f_kernel(GcnParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int FR = F16_FR;
+    constexpr int NP = RES ? 4 : 3;
+    constexpr int FRR = RES == 2 ? FR / 2 : (RES ? FR : 1);
+    constexpr int COG = 16 * COT;
+    float* Wl = smem;                                        // [NP][CIT][4 r][64 lanes][COT]
+    float* stg_all = Wl + NP * CIT * 4 * 64 * COT;           // [8 waves][16 channels][F16_ROW]
+    float* bias = stg_all + 8 * 16 * F16_ROW;                // [COG][16], then the residual conv's bias [COG]
+    double* dacc_all = reinterpret_cast<double*>(bias + COG * 16 + COG);   // [8 waves][2 (y | r)][COG][2]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = lane >> 4, l16 = lane & 15;
+    const int co0 = blockIdx.y * COG;
+    float* stg = stg_all + wave * 16 * F16_ROW;
+    double* dacc = dacc_all + (size_t)wave * 2 * COG * 2;
+    const bool stats = p.ypart != nullptr;
+
+    // The main product is taken TRANSPOSED (the two MFMA operands swapped): lane (q, c) of an output tile holds
+    // y[c][w = 4q .. 4q+3] of its frame - a float4 for the stage, and ONE channel per lane for the statistics.
+    // W fragment = B operand: lane (q, j = c) holds W_k[c][16 tile + 4 q + r].
+    for (int e = tid; e < NP * CIT * 4 * 64 * COT; e += 512) {
+        const int ct = e % COT, ln = (e / COT) & 63, r = (e / (COT * 64)) & 3, tile = (e / (COT * 256)) % CIT,
+                  kk = e / (COT * 256 * CIT);
+        const int c = co0 + 16 * ct + (ln & 15), ci = 16 * tile + 4 * (ln >> 4) + r;
+        float v = 0.f;
+        if (kk < 3) {
+            if (kk < p.K)
+                v = p.w_transposed ? p.w[(size_t)ci * (p.K * p.Co) + kk * p.Co + c] : p.w[((size_t)kk * p.Co + c) * p.Ci + ci];
+        } else {
+            v = p.res_transposed ? p.res_w[(size_t)ci * p.Co + c] : p.res_w[(size_t)c * p.Ci + ci];
+        }
+        Wl[e] = v;
+    }
+    // B operand of the aggregation: A_k[v = 4q + e][w = l16]; the residual's "adjacency" is the identity
+    float akb[NP][4];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) akb[k][e] = (k < p.K) ? p.A[(k * 16 + 4 * q + e) * 16 + l16] : 0.f;
+    if constexpr (RES != 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) akb[NP - 1][e] = (4 * q + e == l16) ? 1.f : 0.f;
+    }
+    for (int e = tid; e < COG * 16; e += 512) {
+        const int c = co0 + (e >> 4), w = e & 15;
+        float s = 0.f;
+        if (p.b)
+            for (int kk = 0; kk < p.K; ++kk) {
+                float cs = 0.f;
+                for (int v = 0; v < 16; ++v) cs += p.A[(kk * 16 + v) * 16 + w];
+                s += p.b[kk * p.Co + c] * cs;
+            }
+        bias[e] = s;
+    }
+    for (int e = tid; e < COG; e += 512) bias[COG * 16 + e] = (RES && p.res_b) ? p.res_b[co0 + e] : 0.f;
+    for (int e = tid; e < 8 * 2 * COG * 2; e += 512) dacc_all[e] = 0.0;
+    __syncthreads();
+
+    // work unit: FR consecutive frames of one sequence (the last unit of a sequence may be short)
+    const int gps = (p.T + FR - 1) / FR;
+    const long long G = (long long)p.N * gps;
+    const long long nw = (long long)gridDim.x * 8, gw = (long long)blockIdx.x * 8 + wave;
+    const long long g0 = G * gw / nw, g1 = G * (gw + 1) / nw;
+    const int ngrp = (int)(g1 - g0);
+    int n = (int)(g0 / gps), tg = (int)(g0 - (long long)n * gps);
+    const unsigned TS = (unsigned)p.T * 64u, TOS = (unsigned)p.To * 64u;
+    const unsigned lane_x = (unsigned)l16 * TS + q * 16u;     // float4 (joints 4q .. 4q+3) of channel l16 (+16 tile)
+    const float* wl = Wl + (size_t)lane * COT;
+
+    // stage -> HBM for one 16-channel tile: 16-byte pieces, FR * 64 contiguous bytes per channel row
+    auto flush = [&](float* base, unsigned row_bytes, int c_first, int f0, int nf) {
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(base);
+#pragma unroll
+        for (int it = 0; it < 16 * FR * 4 / 64; ++it) {
+            const int idx = it * 64 + lane;
+            const int c = idx >> 4, piece = idx & 15;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(stg + c * F16_ROW + piece * 4);
+#ifdef F16_ABL_NOSTORE
+            if (v[0] == 1.2345e30f)
+#else
+            if ((piece >> 2) < nf)
+#endif
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs,
+                                                       (int)((unsigned)(c_first + c) * row_bytes + (unsigned)piece * 16u),
+                                                       (int)((unsigned)f0 * 64u), F16_STORE_AUX);
+        }
+    };
+    // per-lane fp32 sums of this lane's channel 16 ct + l16 (joints 4q .. 4q+3).  Plain v_add_f32 / v_fmac_f32 through
+    // inline asm: left to the compiler the adjacent adds are SLP-packed into v_pk_add_f32 / v_pk_fma_f32, which cost
+    // an MFMA-paced SIMD about three times what two scalar instructions do (MI355X_MICROARCH.md, issue-cost table).
+    float s1[COT], s2[COT], t1[RES ? COT : 1], t2[RES ? COT : 1];
+#pragma unroll
+    for (int ct = 0; ct < COT; ++ct) {
+        s1[ct] = 0.f; s2[ct] = 0.f;
+        if (RES) { t1[ct] = 0.f; t2[ct] = 0.f; }
+    }
+    auto stat4 = [&](float& a, float& b, const f32x4 v) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            asm volatile("v_add_f32 %0, %1, %0" : "+v"(a) : "v"(v[e]));
+            asm volatile("v_fmac_f32 %0, %1, %1" : "+v"(b) : "v"(v[e]));
+        }
+    };
+    auto quad_sum = [&](float v) {                            // over the 4 lanes (q) that share a channel
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        return v;
+    };
+    auto stat_flush = [&]() {
+#pragma unroll
+        for (int ct = 0; ct < COT; ++ct) {
+            const float a = quad_sum(s1[ct]), b = quad_sum(s2[ct]);
+            s1[ct] = 0.f; s2[ct] = 0.f;
+            const int c = 16 * ct + l16;
+            if (q == 0) { dacc[c * 2] += (double)a; dacc[c * 2 + 1] += (double)b; }
+            if constexpr (RES != 0) {
+                const float ar = quad_sum(t1[ct]), br = quad_sum(t2[ct]);
+                t1[ct] = 0.f; t2[ct] = 0.f;
+                if (q == 0) { dacc[(COG + c) * 2] += (double)ar; dacc[(COG + c) * 2 + 1] += (double)br; }
+            }
+        }
+    };
+
+    f32x4 xn[FR];                                             // x fragments of the NEXT tile (or unit), in flight
+    auto load_x = [&](int nn, int t0, int tile) {
+        const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x + (size_t)nn * p.Ci * p.T * 16);
+#pragma unroll
+        for (int f = 0; f < FR; ++f) {
+            const int tt = t0 + f < p.T ? t0 + f : p.T - 1;
+            xn[f] = bload4(rx, lane_x, (unsigned)tt * 64u + (unsigned)tile * 16u * TS);
+        }
+    };
+    if (ngrp > 0) load_x(n, tg * FR, 0);
+
+    for (int i = 0; i < ngrp; ++i) {
+        const int t0 = tg * FR;
+        const int nf = p.T - t0 < FR ? p.T - t0 : FR;
+        int n2 = n, tg2 = tg + 1;
+        if (tg2 == gps) { tg2 = 0; ++n2; }
+        if (i + 1 == ngrp) { n2 = n; tg2 = tg; }              // the last unit prefetches itself: unconditional loads
+        // the accumulators start from the bias term (lane (q, c): bias[c][4q .. 4q+3]): no add in the epilogue
+        f32x4 acc[FR][COT], accr[FRR][COT];
+#pragma unroll
+        for (int ct = 0; ct < COT; ++ct) {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + (16 * ct + l16) * 16 + 4 * q);
+#pragma unroll
+            for (int f = 0; f < FR; ++f) acc[f][ct] = bv;
+            if constexpr (RES != 0) {
+                const float br = bias[COG * 16 + 16 * ct + l16];
+#pragma unroll
+                for (int f = 0; f < FRR; ++f) accr[f][ct] = f32x4{br, br, br, br};
+            }
+        }
+#pragma unroll
+        for (int tile = 0; tile < CIT; ++tile) {
+            f32x4 xq[FR];
+#pragma unroll
+            for (int f = 0; f < FR; ++f) xq[f] = xn[f];
+            if (tile + 1 < CIT) load_x(n, t0, tile + 1);
+            else load_x(n2, tg2 * FR, 0);
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                // W fragments of (partition, tile): 4 k-steps x COT output tiles, read once for the 4 frames
+                float wf[4][COT];
+                const float* wk = wl + (size_t)((k * CIT + tile) * 4) * 64 * COT;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if constexpr (COT == 4) {
+                        const f32x4 a = *reinterpret_cast<const f32x4*>(wk + (size_t)r * 64 * COT);
+                        wf[r][0] = a[0]; wf[r][1] = a[1]; wf[r][2] = a[2]; wf[r][3] = a[3];
+                    } else {
+                        wf[r][0] = wk[(size_t)r * 64 * COT]; wf[r][1] = wk[(size_t)r * 64 * COT + 1];
+                    }
+                }
+                // the aggregation of the 4 frames as 4 interleaved chains (D register r of lane (q, w) =
+                // z_k[16 tile + 4 q + r][w]), then the main product with z as the A operand
+                // (two frames at a time: the z registers of a pair are dead before the next pair's chains start)
+#pragma unroll
+                for (int fp = 0; fp < FR; fp += 2) {
+                    f32x4 z[2];
+#pragma unroll
+                    for (int f = 0; f < 2; ++f) z[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int f = 0; f < 2; ++f) {
+                            if (k == 3 && RES == 2 && (f & 1)) continue;     // (stride 2: odd frames are not outputs)
+                            z[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(xq[fp + f][e], akb[k][e], z[f], 0, 0, 0);
+                        }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int f = 0; f < 2; ++f) {
+                            if (k == 3 && RES == 2 && (f & 1)) continue;
+#pragma unroll
+                            for (int ct = 0; ct < COT; ++ct) {
+                                if (k < 3)
+                                    acc[fp + f][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(z[f][r], wf[r][ct], acc[fp + f][ct], 0, 0, 0);
+                                else if constexpr (RES != 0) {
+                                    constexpr int sh = RES == 2 ? 1 : 0;
+                                    accr[(fp + f) >> sh][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(z[f][r], wf[r][ct], accr[(fp + f) >> sh][ct], 0, 0, 0);
+                                }
+                            }
+                        }
+                }
+            }
+        }
+#pragma unroll
+        for (int ct = 0; ct < COT; ++ct) {
+#pragma unroll
+            for (int f = 0; f < FR; ++f)
+                *reinterpret_cast<f32x4*>(stg + l16 * F16_ROW + f * 16 + 4 * q) = acc[f][ct];
+#ifndef F16_ABL_NOSTATS
+            if (stats) {
+#pragma unroll
+                for (int f = 0; f < FR; ++f)
+                    if (f < nf) stat4(s1[ct], s2[ct], acc[f][ct]);
+            }
+#endif
+            flush(p.y + (size_t)n * p.Co * p.T * 16, TS, co0 + 16 * ct, t0, nf);
+        }
+        if constexpr (RES != 0) {
+            constexpr int st = RES;
+            const int nfr = (nf + st - 1) / st;
+#pragma unroll
+            for (int ct = 0; ct < COT; ++ct) {
+#pragma unroll
+                for (int f = 0; f < FRR; ++f)
+                    *reinterpret_cast<f32x4*>(stg + l16 * F16_ROW + f * 16 + 4 * q) = accr[f][ct];
+#ifndef F16_ABL_NOSTATS
+                if (stats) {
+#pragma unroll
+                    for (int f = 0; f < FRR; ++f)
+                        if (f < nfr) stat4(t1[ct], t2[ct], accr[f][ct]);
+                }
+#endif
+                flush(p.res_out + (size_t)n * p.Co * p.To * 16, TOS, co0 + 16 * ct, t0 / st, nfr);
+            }
+        }
+        if (stats && ((i + 1) % STAT_FLUSH == 0)) stat_flush();
+        n = n2; tg = tg2;
+    }
+    if (stats) {
+        stat_flush();
+        __syncthreads();
+        // ordered sum over the 8 waves; partial layout of bn.hip: [block][channel of Co][2]
+        for (int e = tid; e < 2 * COG * 2; e += 512) {
+            double s = 0.0;
+#pragma unroll
+            for (int w8 = 0; w8 < 8; ++w8) s += dacc_all[(size_t)w8 * 2 * COG * 2 + e];
+            const int which = e / (COG * 2), ce = e % (COG * 2);          // y | r, (channel, sum | sum of squares)
+            double* dst = which ? p.rpart : p.ypart;
+            if (dst) dst[((size_t)blockIdx.x * p.Co + co0) * 2 + ce] = s;
+        }
+    }
+}
+
+size_t gcn16f_lds(int cit, int cot, int np) {
+    return ((size_t)np * cit * 4 * 64 * cot + 8 * 16 * F16_ROW + 16 * cot * 17) * sizeof(float) +
+           (size_t)8 * 2 * 16 * cot * 2 * sizeof(double);
+}
+
+// blocks of the fourth form (also the number of statistic partials per channel): one 512-thread block per CU
+int gcn16f_blocks(int N, int T, int groups) {
+    const long long units = (long long)N * ((T + F16_FR - 1) / F16_FR);
+    long long b = (units + 7) / 8;
+    const long long cap = 256 / groups > 0 ? 256 / groups : 1;
+    return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+// Ci, Co in {32, 64}; -2: shape not covered (the other forms take it)
+int launch_gcn16f(const GcnParams& p, hipStream_t st) {
+    if ((p.Ci != 32 && p.Ci != 64) || (p.Co != 32 && p.Co != 64) || p.in_scale) return -2;
+    const int res = p.res_w ? p.stride : 0;
+    const int cot = p.Co / 16, cit = p.Ci / 16;
+    if (cot == 4 && res == 1) return -2;                      // 4 frames x (4 + 4) accumulator tiles do not fit
+    const size_t lds = gcn16f_lds(cit, cot, res ? 4 : 3);
+    const int b = gcn16f_blocks(p.N, p.T, 1);
+    auto go = [&](auto kern) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            step::set_error("step_gcn_fwd: hipFuncSetAttribute(%zu): %s", lds, hipGetErrorString(e));
+            return (int)STEP_ERR_LAUNCH;
+        }
+        hipLaunchKernelGGL(kern, dim3((unsigned)b, 1), dim3(512), lds, st, p);
+        return step::check_launch("step_gcn_fwd(4-frame form)");
+    };
+#define F16_CASE(CITV, COTV, RESV) if (cit == CITV && cot == COTV && res == RESV) return go(gcn_fwd16f_kernel<CITV, COTV, RESV>)
+    F16_CASE(2, 2, 0); F16_CASE(2, 2, 1); F16_CASE(2, 2, 2);
+    F16_CASE(2, 4, 0); F16_CASE(2, 4, 2);
+    F16_CASE(4, 2, 0); F16_CASE(4, 2, 1); F16_CASE(4, 2, 2);
+    F16_CASE(4, 4, 0); F16_CASE(4, 4, 2);
+#undef F16_CASE
+    return -2;
+}
+
 // output-channel group of a wide launch: the largest of 128 / 64 / 32 that divides Co and whose W slice fits LDS
 int gcn16_cog(int Ci, int Co, bool res) {
     const int np = res ? 4 : 3;
@@ -1134,10 +1469,11 @@ int launch_gcn_small(const GcnParams& p, hipStream_t st) {
 }  // namespace
 
 namespace {
+// *fused_stats: in: statistic partials wanted (ypart / rpart below); out: whether the launched form wrote them
 int gcn_fwd(const float* x, const float* in_scale, const float* in_shift, const float* w, const float* b,
             int w_transposed, const float* A_eff, int a_nnz_max, float* y, const float* res_w, const float* res_b,
             int res_transposed, float* res_out, int N, int Ci, int Co, int K, int T, int stride, bool split,
-            void* stream) {
+            void* stream, double* ypart = nullptr, double* rpart = nullptr, int* stat_blocks = nullptr) {
     STEP_REQUIRE(x && w && A_eff && y, "step_gcn_fwd: null pointer");
     STEP_REQUIRE(N > 0 && Ci > 0 && Co > 0 && T > 0, "step_gcn_fwd: bad shape N=%d Ci=%d Co=%d T=%d", N,
                  Ci, Co, T);
@@ -1166,6 +1502,18 @@ int gcn_fwd(const float* x, const float* in_scale, const float* in_shift, const 
     if (split && !in_scale && Ci % 16 == 0 && Co % 32 == 0 && Ci <= 256 && Co <= 256) {
         const int rc = launch_gcn16s(p, st);
         if (rc != -2) return rc;
+    }
+    // round 3: the 4-frame form for the reference's inner widths (Ci, Co in {32, 64}); STEP_GCN_FWD_OLD=1 keeps the
+    // second / third forms (A/B runs and the cross-check test)
+    if (stat_blocks) *stat_blocks = 0;
+    if (!getenv("STEP_GCN_FWD_OLD") && !getenv("STEP_GCN_FWD_V1") && !split) {
+        p.ypart = ypart; p.rpart = rpart;
+        const int rc = launch_gcn16f(p, st);
+        if (rc != -2) {
+            if (stat_blocks && ypart) *stat_blocks = gcn16f_blocks(N, T, 1);
+            return rc;
+        }
+        p.ypart = p.rpart = nullptr;
     }
     if (wide) return launch_gcn16(p, st);
     if (Ci <= 4 && (Co == 32 || Co == 64) && !getenv("STEP_GCN_FWD_V1"))
@@ -1196,4 +1544,39 @@ extern "C" int step_gcn_fwd_split(const float* x, const float* in_scale, const f
                                   int stride, void* stream) {
     return gcn_fwd(x, in_scale, in_shift, w, b, w_transposed, A_eff, a_nnz_max, y, res_w, res_b, res_transposed,
                    res_out, N, Ci, Co, K, T, stride, true, stream);
+}
+
+extern "C" size_t step_gcn_fwd_stats_ws_bytes(int Co) { return Co > 0 ? 2 * step_bn_ws_bytes(Co) : 0; }
+
+extern "C" int step_gcn_fwd_stats(const float* x, const float* in_scale, const float* in_shift,
+                                  const float* w, const float* b, int w_transposed, const float* A_eff,
+                                  int a_nnz_max, float* y, const float* res_w, const float* res_b,
+                                  int res_transposed, float* res_out, int N, int Ci, int Co, int K, int T,
+                                  int stride, double* y_sums, double* r_sums, void* ws, size_t ws_bytes,
+                                  void* stream) {
+    STEP_REQUIRE(y_sums && ws, "step_gcn_fwd_stats: null pointer");
+    STEP_REQUIRE((res_w == nullptr) == (r_sums == nullptr), "step_gcn_fwd_stats: r_sums comes with the residual conv");
+    const size_t half = step_bn_ws_bytes(Co);
+    if (ws_bytes < 2 * half) {
+        step::set_error("step_gcn_fwd_stats: workspace %zu < %zu bytes", ws_bytes, 2 * half);
+        return STEP_ERR_WORKSPACE;
+    }
+    double* ypart = (double*)ws;
+    double* rpart = res_w ? (double*)((char*)ws + half) : nullptr;
+    int blocks = 0;
+    int rc = gcn_fwd(x, in_scale, in_shift, w, b, w_transposed, A_eff, a_nnz_max, y, res_w, res_b, res_transposed,
+                     res_out, N, Ci, Co, K, T, stride, false, stream, ypart, rpart, &blocks);
+    if (rc != STEP_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    if (blocks > 0) {
+        // statistics taken in the producer's epilogue: one fp64 partial per (block, channel), summed in order
+        rc = step::bn_sum_partials(ypart, y_sums, Co, blocks, st);
+        if (rc == STEP_OK && rpart) rc = step::bn_sum_partials(rpart, r_sums, Co, blocks, st);
+        return rc;
+    }
+    // forms without the epilogue: the separate statistics passes, same results layout
+    rc = step_bn_train_stats(y, N, Co, T, STEP_V, 0, y_sums, ws, half, stream);
+    if (rc == STEP_OK && res_w)
+        rc = step_bn_train_stats(res_out, N, Co, (T - 1) / stride + 1, STEP_V, 0, r_sums, (char*)ws + half, half, stream);
+    return rc;
 }

@@ -50,6 +50,34 @@ def _sync_sums(sums):
     parallel._all_reduce_sum(sums, _SYNC_BN["group"])
 
 
+def _sync_many(bufs):
+    """ONE all-reduce for several [sums..., count] buffers (statistics of BatchNorms whose inputs exist at the same
+    time: tcn[0] and residual[1] after the graph conv, tcn[3] and residual[1] in the block's backward tail)"""
+    if len(bufs) == 1:
+        _sync_sums(bufs[0])
+        return
+    flat = torch.cat(bufs)
+    _sync_sums(flat)
+    off = 0
+    for b in bufs:
+        b.copy_(flat[off:off + b.numel()])
+        off += b.numel()
+
+
+def bn_finalize_sums(sums, count, bn, synced, momentum=BN_MOMENTUM):
+    """(mean, invstd, scale, shift) + running-stat update from [SUM x, SUM x^2] per group (2G doubles, slot 2G = the
+    element count when the sums were combined over ranks): the second half of step_bn_train_prepare, for
+    statistics a producer kernel took in its epilogue (step_gcn_fwd_stats)"""
+    G = bn.weight.numel()
+    dev = sums.device
+    mean = torch.empty(G, dtype=torch.float32, device=dev)
+    invstd, scale, shift = torch.empty_like(mean), torch.empty_like(mean), torch.empty_like(mean)
+    _lib.call("step_bn_train_finalize", sums, 0.0 if synced else float(count), bn.weight, bn.bias, bn.running_mean,
+              bn.running_var, momentum, BN_EPS, mean, invstd, scale, shift, G)
+    bn.num_batches_tracked += 1
+    return mean, invstd, scale, shift
+
+
 def bn_eval_prepare(weight, bias, running_mean, running_var):
     G = running_mean.numel()
     scale = torch.empty(G, dtype=torch.float32, device=running_mean.device)
@@ -135,6 +163,37 @@ def bn_backward(dy, x, mask_src, scale, shift, mask_mode, mean, invstd, gamma, t
     _lib.call("step_bn_bwd_apply", dy, x, mask_src, scale, shift, mask_mode, mean, invstd, gamma, sums,
               int(training), accumulate, dx, dgamma, dbeta, N, C, T, V, bn_mode, ws, nb)
     return dx, dgamma, dbeta
+
+
+def bn_backward_tail_synced(dout, out, u, r, m2, i2, g2, mr, ir, gr):
+    """bn_backward_tail_pair under synchronised BatchNorm: the two reduces, ONE all-reduce of both [SUM g, SUM g*x,
+    count] buffers, the two applies (dgamma / dbeta from this rank's sums, dx from the combined ones)"""
+    N, C, T, V = u.shape
+    dev = u.device
+    nb = _lib.query("step_bn_ws_bytes", C)
+    local = float(N * T * V)
+    res = []
+    bufs = []
+    for x, mean, invstd, gamma in ((u, m2, i2, g2), (r, mr, ir, gr)):
+        ws = _ws(nb, dev)
+        sums = torch.empty(2 * C + 1, dtype=torch.float64, device=dev)
+        _lib.call("step_bn_bwd_reduce", dout, x, out, None, None, 1, N, C, T, V, 0, sums, ws, nb)
+        dgamma = torch.empty(C, dtype=torch.float32, device=dev)
+        dbeta = torch.empty_like(dgamma)
+        _lib.call("step_bn_bwd_apply", dout, x, out, None, None, 1, mean, invstd, gamma, sums,
+                  1, 0, None, dgamma, dbeta, N, C, T, V, 0, ws, nb)
+        sums[2 * C] = local
+        bufs.append(sums)
+        res.append([x, mean, invstd, gamma, ws, dgamma, dbeta])
+    _sync_many(bufs)
+    outs = []
+    for sums, (x, mean, invstd, gamma, ws, dgamma, dbeta) in zip(bufs, res):
+        sums[:2 * C] *= local / sums[2 * C]
+        dx = torch.empty_like(x)
+        _lib.call("step_bn_bwd_apply", dout, x, out, None, None, 1, mean, invstd, gamma, sums,
+                  1, 0, dx, None, None, N, C, T, V, 0, ws, nb)
+        outs += [dx, dgamma, dbeta]
+    return tuple(outs)
 
 
 def bn_backward_tail_pair(dout, out, u, r, m2, i2, g2, mr, ir, gr, training):
@@ -296,10 +355,28 @@ class StGcnBlockFn(torch.autograd.Function):
 
         y = torch.empty((N, Co, T, 16), dtype=torch.float32, device=dev)
         r = torch.empty((N, Co, To, 16), dtype=torch.float32, device=dev) if res_w is not None else None
-        _lib.call(s.gcn_fwd, x, s0, h0, gcn_w, gcn_b, int(s.transposed), A_eff, s.nnz, y,
-                  res_w, res_b, int(s.transposed), r, N, Ci, Co, K, T, st)
-
-        m1, i1, s1, h1 = bn_prepare(y, 0, s.bn1, training)
+        rstats = None
+        if training and s.gcn_fwd == "step_gcn_fwd":
+            # train mode: the graph conv also returns SUM y, SUM y^2 (and the residual conv's) per channel - taken in
+            # its epilogue where that kernel form exists, so BN1 / the residual BN never read y / r for statistics
+            ysums = torch.empty(2 * Co + 1, dtype=torch.float64, device=dev)
+            rsums = torch.empty(2 * Co + 1, dtype=torch.float64, device=dev) if res_w is not None else None
+            nbw = _lib.query("step_gcn_fwd_stats_ws_bytes", Co)
+            _lib.call("step_gcn_fwd_stats", x, s0, h0, gcn_w, gcn_b, int(s.transposed), A_eff, s.nnz, y,
+                      res_w, res_b, int(s.transposed), r, N, Ci, Co, K, T, st, ysums, rsums, _ws(nbw, dev), nbw)
+            synced = _sync_world() > 1
+            if synced:
+                ysums[2 * Co] = float(N * T * 16)
+                if rsums is not None:
+                    rsums[2 * Co] = float(N * To * 16)
+                _sync_many([ysums] if rsums is None else [ysums, rsums])
+            m1, i1, s1, h1 = bn_finalize_sums(ysums, N * T * 16, s.bn1, synced)
+            if rsums is not None:
+                rstats = bn_finalize_sums(rsums, N * To * 16, s.bnr, synced)
+        else:
+            _lib.call(s.gcn_fwd, x, s0, h0, gcn_w, gcn_b, int(s.transposed), A_eff, s.nnz, y,
+                      res_w, res_b, int(s.transposed), r, N, Ci, Co, K, T, st)
+            m1, i1, s1, h1 = bn_prepare(y, 0, s.bn1, training)
         mode = 1 if s.transposed else 0
         bf = s.bf16_fwd
         wp = tcn_pack(tcn_w, Co, Co, Kt, st, mode, bf16=bf)
@@ -323,7 +400,7 @@ class StGcnBlockFn(torch.autograd.Function):
         m2, i2, s2, h2 = bn_prepare(u, 0, s.bn2, training)
         res_t = None
         if s.residual == "conv":
-            mr, ir, sr, hr = bn_prepare(r, 0, s.bnr, training)
+            mr, ir, sr, hr = rstats if rstats is not None else bn_prepare(r, 0, s.bnr, training)
             res_t = r
         elif s.residual == "identity":
             res_t = x
@@ -353,9 +430,9 @@ class StGcnBlockFn(torch.autograd.Function):
         if s.residual == "conv" and not (training and _sync_world() > 1):
             du, dg2, db2, dr, dgr, dbr = bn_backward_tail_pair(dout, out, u, r, m2, i2, bn2_w, mr, ir, bnr_w, training)
         elif s.residual == "conv":
-            # synchronised BatchNorm: the fused pair cannot stop between its reduce and its apply for the all-reduce
-            du, dg2, db2 = bn_backward(dout, u, out, None, None, 1, m2, i2, bn2_w, training, 0)
-            dr, dgr, dbr = bn_backward(dout, r, out, None, None, 1, mr, ir, bnr_w, training, 0)
+            # synchronised BatchNorm: the fused pair cannot stop between its reduce and its apply for the all-reduce;
+            # its two halves share ONE all-reduce
+            du, dg2, db2, dr, dgr, dbr = bn_backward_tail_synced(dout, out, u, r, m2, i2, bn2_w, mr, ir, bnr_w)
         else:
             du, dg2, db2 = bn_backward(dout, u, out, None, None, 1, m2, i2, bn2_w, training, 0)
 

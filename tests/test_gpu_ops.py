@@ -564,3 +564,53 @@ def test_wgrad_nan_input_without_relu_stays_non_finite(bf16):
     assert not bool(torch.isfinite(dw[:, 5]).all()), "a NaN activation vanished from the weight gradient"
     others = torch.cat((dw[:, :5], dw[:, 6:]), dim=1)
     assert bool(torch.isfinite(others).all()) and bool(torch.isfinite(db).all())
+
+
+@pytest.mark.parametrize("Ci,Co,T,N,stride,res,tr", [
+    (32, 64, 75, 5, 2, True, False), (64, 64, 41, 3, 1, False, False), (64, 32, 29, 4, 1, True, False),
+    (32, 32, 13, 4, 1, False, True), (32, 64, 240, 40, 2, True, False), (64, 64, 120, 37, 1, False, False),
+    (3, 32, 30, 6, 1, True, False), (32, 64, 9, 3, 1, True, True), (64, 128, 10, 2, 2, True, False)])
+def test_gcn_fwd_stats_epilogue(Ci, Co, T, N, stride, res, tr):
+    """step_gcn_fwd_stats: outputs bit-equal to step_gcn_fwd's, and [SUM, SUM of squares] per channel of y and of the
+    residual conv's output equal to float64 sums of those tensors (shapes with the epilogue form, T % 4 != 0, odd T
+    under stride 2, and shapes that take the separate statistics pass: first block, stride-1 residual at 64 wide,
+    wide layers); two calls give bit-identical sums"""
+    from step_amd import _lib, ops
+    d = dev()
+    g = torch.Generator().manual_seed(Ci * 1000 + Co + T)
+    A = A_spatial().to(d)
+    nnz = ops.a_nnz_max(A)
+    To = (T - 1) // stride + 1
+    x = (torch.randn(N, Ci, T, 16, generator=g) + 0.3).to(d)
+    w = (torch.randn(Ci, 3 * Co, generator=g) if tr else torch.randn(3 * Co, Ci, generator=g)).to(d) * 0.2
+    b = torch.randn(3 * Co, generator=g).to(d)
+    rw = ((torch.randn(Ci, Co, generator=g) if tr else torch.randn(Co, Ci, generator=g)).to(d) * 0.2) if res else None
+    rb = torch.randn(Co, generator=g).to(d) if res else None
+
+    def run(stats):
+        y = torch.full((N, Co, T, 16), float("nan"), device=d)
+        r = torch.full((N, Co, To, 16), float("nan"), device=d) if res else None
+        if not stats:
+            _lib.call("step_gcn_fwd", x, None, None, w, b, int(tr), A, nnz, y, rw, rb, int(tr), r, N, Ci, Co, 3, T, stride)
+            return y, r, None, None
+        ys = torch.zeros(2 * Co + 1, dtype=torch.float64, device=d)
+        rs = torch.zeros(2 * Co + 1, dtype=torch.float64, device=d) if res else None
+        nb = _lib.query("step_gcn_fwd_stats_ws_bytes", Co)
+        ws = torch.empty(nb, dtype=torch.uint8, device=d)
+        _lib.call("step_gcn_fwd_stats", x, None, None, w, b, int(tr), A, nnz, y, rw, rb, int(tr), r, N, Ci, Co, 3, T,
+                  stride, ys, rs, ws, nb)
+        return y, r, ys, rs
+
+    y0, r0, _, _ = run(False)
+    y1, r1, ys, rs = run(True)
+    y2, r2, ys2, rs2 = run(True)
+    assert torch.equal(y0, y1) and (not res or torch.equal(r0, r1))
+    assert torch.equal(ys, ys2) and (not res or torch.equal(rs, rs2))
+    for t, sm, name in ((y1, ys, "y"), (r1, rs, "r")):
+        if t is None:
+            continue
+        td = t.double()
+        ref1, ref2 = td.sum(dim=(0, 2, 3)), (td * td).sum(dim=(0, 2, 3))
+        got = sm[:2 * Co].view(Co, 2)
+        assert float((got[:, 0] - ref1).abs().max()) <= 2e-6 * float(td.abs().sum(dim=(0, 2, 3)).max()), name
+        assert float(((got[:, 1] - ref2) / ref2).abs().max()) <= 2e-6, name

@@ -58,10 +58,17 @@ def main():
     nb = _lib.query("step_gcn_bwd_ws_bytes", N, Ci, Co, K, T)
     ws = torch.empty(nb, dtype=torch.uint8, device=d)
     el = 4.0
+    ysums = torch.empty(2 * Co + 1, dtype=torch.float64, device=d)
+    rsums = torch.empty(2 * Co + 1, dtype=torch.float64, device=d) if resconv else None
+    snb = _lib.query("step_gcn_fwd_stats_ws_bytes", Co)
+    sws = torch.empty(snb, dtype=torch.uint8, device=d)
     calls = {
         "gcn_fwd": (lambda: _lib.call("step_gcn_fwd", x, None, None, w, b, 0, A, nnz, y, rw, rb, 0, r,
                                       N, Ci, Co, K, T, st),
                     el * (x.numel() + y.numel() + (r.numel() if resconv else 0))),
+        "gcn_fwd_stats": (lambda: _lib.call("step_gcn_fwd_stats", x, None, None, w, b, 0, A, nnz, y, rw, rb, 0, r,
+                                            N, Ci, Co, K, T, st, ysums, rsums, sws, snb),
+                          el * (x.numel() + y.numel() + (r.numel() if resconv else 0))),
         "gcn_fwd_split": (lambda: _lib.call("step_gcn_fwd_split", x, None, None, w, b, 0, A, nnz, y, rw, rb, 0, r,
                                             N, Ci, Co, K, T, st),
                           el * (x.numel() + y.numel() + (r.numel() if resconv else 0))),
@@ -90,7 +97,7 @@ def main():
         lambda: ops.bn_backward(dy, y, None, sc, sh, 2, mean, invstd, bnw, True, 0),
         el * (2 * 2 * dy.numel() + dy.numel()))
     for name, (fn, nbytes) in calls.items():
-        if a.only and not name.startswith(a.only):
+        if a.only and not (name + " ").startswith(a.only):
             continue
         ms = timeit(fn, a.reps)
         print("%-24s blk%d N=%d: %8.3f ms  %7.1f GB/s algorithmic (%.2f of 8 TB/s)" %
