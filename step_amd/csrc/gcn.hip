@@ -1298,7 +1298,7 @@ int launch_gcn16s(const GcnParams& p, hipStream_t st) {
 //                                          (B = z_q, selected per lane), step e supplies channel e
 //   r[c][w]    = SUM_ci Wr[c,ci] x'[ci,w]  one MFMA per 16 output channels
 template <int COT>
-__global__ __launch_bounds__(512, COT == 2 ? 4 : 2) void gcn_fwd_small_kernel(GcnParams p) {
+__global__ __launch_bounds__(512, 2) void gcn_fwd_small_kernel(GcnParams p) {
     constexpr int CO = 16 * COT;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1357,6 +1357,38 @@ __global__ __launch_bounds__(512, COT == 2 ? 4 : 2) void gcn_fwd_small_kernel(Gc
     constexpr int FR = 4;
     __shared__ __attribute__((aligned(16))) float stage_all[8][CO * FR * 16];
     float* stg = stage_all[wave];
+    // optional BatchNorm statistics of y and of the residual conv's output (p.ypart != NULL), as in the fourth form:
+    // per-lane fp32 sums of channel 16 ct + 4 q + r at joint l16 over at most STAT_FLUSH units, then fp64 per wave
+    __shared__ double dacc_all[8][2][CO][2];
+    double* dacc = &dacc_all[wave][0][0][0];
+    const bool stats = p.ypart != nullptr;
+    for (int e = tid; e < 8 * 2 * CO * 2; e += 512) (&dacc_all[0][0][0][0])[e] = 0.0;
+    __syncthreads();
+    float s1[COT][4], s2[COT][4], t1[COT][4], t2[COT][4];
+#pragma unroll
+    for (int ct = 0; ct < COT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s1[ct][r] = 0.f; s2[ct][r] = 0.f; t1[ct][r] = 0.f; t2[ct][r] = 0.f; }
+    auto stat1 = [&](float& sa, float& sb, float v) {
+        asm volatile("v_add_f32 %0, %1, %0" : "+v"(sa) : "v"(v));
+        asm volatile("v_fmac_f32 %0, %1, %1" : "+v"(sb) : "v"(v));
+    };
+    auto stat_flush = [&]() {
+#pragma unroll
+        for (int ct = 0; ct < COT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = 16 * ct + 4 * q + r;
+                const float a = row16_sum(s1[ct][r]), b2 = row16_sum(s2[ct][r]);
+                s1[ct][r] = 0.f; s2[ct][r] = 0.f;
+                if (l16 == 0) { dacc[c * 2] += (double)a; dacc[c * 2 + 1] += (double)b2; }
+                if (has_res) {
+                    const float ar = row16_sum(t1[ct][r]), br2 = row16_sum(t2[ct][r]);
+                    t1[ct][r] = 0.f; t2[ct][r] = 0.f;
+                    if (l16 == 0) { dacc[(CO + c) * 2] += (double)ar; dacc[(CO + c) * 2 + 1] += (double)br2; }
+                }
+            }
+    };
     const int gps = (p.T + FR - 1) / FR;
     const long long G = (long long)p.N * gps;
     const long long nw = (long long)gridDim.x * 8, gw = (long long)blockIdx.x * 8 + wave;
@@ -1419,6 +1451,10 @@ __global__ __launch_bounds__(512, COT == 2 ? 4 : 2) void gcn_fwd_small_kernel(Gc
                     if (e < Ci) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wA[ct][e], zs[e], acc, 0, 0, 0);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) stg[(16 * ct + 4 * q + r) * (FR * 16) + f * 16 + l16] = acc[r];
+                if (stats && f < nf) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) stat1(s1[ct][r], s2[ct][r], acc[r]);
+                }
             }
         }
         flush(p.y + (size_t)nn * CO * p.T * 16, TS, t0, nf);
@@ -1435,6 +1471,10 @@ __global__ __launch_bounds__(512, COT == 2 ? 4 : 2) void gcn_fwd_small_kernel(Gc
                     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wrA[ct], xds[f], acc, 0, 0, 0);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) stg[(16 * ct + 4 * q + r) * (FR * 16) + fo * 16 + l16] = acc[r];
+                    if (stats && f < nf) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) stat1(t1[ct][r], t2[ct][r], acc[r]);
+                    }
                 }
             }
             flush(p.res_out + (size_t)nn * CO * p.To * 16, TOS, t0 / st, (nf + st - 1) / st);
@@ -1454,14 +1494,31 @@ __global__ __launch_bounds__(512, COT == 2 ? 4 : 2) void gcn_fwd_small_kernel(Gc
             if (i + 2 < ngrp) load_grp(n, tg * FR, ga);
             do_grp(n1, tg1 * FR, gb);
         }
+        if (stats && ((i / 2 + 1) % (STAT_FLUSH / 2) == 0)) stat_flush();
     }
+    if (stats) {
+        stat_flush();
+        __syncthreads();
+        for (int e = tid; e < 2 * CO * 2; e += 512) {
+            double sum = 0.0;
+#pragma unroll
+            for (int w8 = 0; w8 < 8; ++w8) sum += (&dacc_all[w8][0][0][0])[e];
+            const int which = e / (CO * 2), ce = e % (CO * 2);
+            double* dst = which ? p.rpart : p.ypart;
+            if (dst) dst[(size_t)blockIdx.x * CO * 2 + ce] = sum;
+        }
+    }
+}
+
+int gcn_small_blocks(int N, int T) {
+    const long long grps = (long long)N * ((T + 3) / 4);
+    long long b = (grps + 15) / 16;
+    return (int)(b < 1 ? 1 : (b > 512 ? 512 : b));
 }
 
 template <int COT>
 int launch_gcn_small(const GcnParams& p, hipStream_t st) {
-    const long long grps = (long long)p.N * ((p.T + 3) / 4);
-    long long b = (grps + 15) / 16;
-    b = b < 1 ? 1 : (b > 512 ? 512 : b);
+    const int b = gcn_small_blocks(p.N, p.T);
     hipLaunchKernelGGL((gcn_fwd_small_kernel<COT>), dim3((unsigned)b), dim3(512), 0, st, p);
     return step::check_launch("step_gcn_fwd(first block)");
 }
@@ -1516,8 +1573,13 @@ int gcn_fwd(const float* x, const float* in_scale, const float* in_shift, const 
         p.ypart = p.rpart = nullptr;
     }
     if (wide) return launch_gcn16(p, st);
-    if (Ci <= 4 && (Co == 32 || Co == 64) && !getenv("STEP_GCN_FWD_V1"))
+    if (Ci <= 4 && (Co == 32 || Co == 64) && !getenv("STEP_GCN_FWD_V1")) {
+        if (!split && !getenv("STEP_GCN_FWD_OLD")) {             // first block: statistics in the epilogue too
+            p.ypart = ypart; p.rpart = rpart;
+            if (stat_blocks && ypart) *stat_blocks = gcn_small_blocks(N, T);
+        }
         return Co == 32 ? launch_gcn_small<2>(p, st) : launch_gcn_small<4>(p, st);
+    }
     const int mt = p.Copad / 32;
     if (!in_scale && (Ci == 32 || Ci == 64) && !getenv("STEP_GCN_FWD_V1")) {
         const int rc = Ci == 32 ? dispatch_gcn2<32>(p, st) : dispatch_gcn2<64>(p, st);
@@ -1546,7 +1608,13 @@ extern "C" int step_gcn_fwd_split(const float* x, const float* in_scale, const f
                    res_out, N, Ci, Co, K, T, stride, true, stream);
 }
 
-extern "C" size_t step_gcn_fwd_stats_ws_bytes(int Co) { return Co > 0 ? 2 * step_bn_ws_bytes(Co) : 0; }
+// half a workspace: 512 blocks of partials [Co][2] doubles (the first block's form launches up to 512), which also
+// covers step_bn_ws_bytes(Co) for the shapes that take the separate statistics pass
+static size_t stats_half(int Co) {
+    const size_t a = (size_t)512 * Co * 2 * sizeof(double) + 64 * (size_t)Co, b = step_bn_ws_bytes(Co);
+    return a > b ? a : b;
+}
+extern "C" size_t step_gcn_fwd_stats_ws_bytes(int Co) { return Co > 0 ? 2 * stats_half(Co) : 0; }
 
 extern "C" int step_gcn_fwd_stats(const float* x, const float* in_scale, const float* in_shift,
                                   const float* w, const float* b, int w_transposed, const float* A_eff,
@@ -1556,7 +1624,8 @@ extern "C" int step_gcn_fwd_stats(const float* x, const float* in_scale, const f
                                   void* stream) {
     STEP_REQUIRE(y_sums && ws, "step_gcn_fwd_stats: null pointer");
     STEP_REQUIRE((res_w == nullptr) == (r_sums == nullptr), "step_gcn_fwd_stats: r_sums comes with the residual conv");
-    const size_t half = step_bn_ws_bytes(Co);
+    STEP_REQUIRE(Co > 0, "step_gcn_fwd_stats: Co=%d", Co);
+    const size_t half = stats_half(Co);
     if (ws_bytes < 2 * half) {
         step::set_error("step_gcn_fwd_stats: workspace %zu < %zu bytes", ws_bytes, 2 * half);
         return STEP_ERR_WORKSPACE;
