@@ -139,9 +139,15 @@ def time_hbm_kernels(n, t, device, reps=3):
         rm, rv = torch.zeros(co, device=device), torch.ones(co, device=device)
         mean, invstd, sc, sh = ops.bn_train_prepare(dy, 0, bnw, bnb, rm, rv)
         rn = r.numel() if resconv else 0
+        ysums = torch.empty(2 * co + 1, dtype=torch.float64, device=device)
+        rsums = torch.empty(2 * co + 1, dtype=torch.float64, device=device) if resconv else None
+        snb = _lib.query("step_gcn_fwd_stats_ws_bytes", co)
+        sws = torch.empty(snb, dtype=torch.uint8, device=device)
         calls = {
-            "gcn_fwd": (lambda: _lib.call("step_gcn_fwd", x, None, None, w, b, 0, A, nnz, y, rw, rb, 0, r,
-                                          n, ci, co, 3, tt, st), x.numel() + y.numel() + rn),
+            # the train step's call: graph conv + residual conv WITH the BatchNorm statistics of both outputs in the
+            # epilogue (step_gcn_fwd_stats); FLOPs / bytes counted are the convolution's alone
+            "gcn_fwd": (lambda: _lib.call("step_gcn_fwd_stats", x, None, None, w, b, 0, A, nnz, y, rw, rb, 0, r,
+                                          n, ci, co, 3, tt, st, ysums, rsums, sws, snb), x.numel() + y.numel() + rn),
             "gcn_bwd": (lambda: _lib.call("step_gcn_bwd", dy, dr, x, None, None, w, b, 0, A, nnz, rw, 0, dx, dw, db,
                                           dA, drw, drb, n, ci, co, 3, tt, st, ws, nb),
                         2 * (x.numel() + dy.numel() + rn) + dx.numel()),

@@ -330,6 +330,11 @@ int step_dense_fwd(const float* x, const float* w, const float* b, int w_transpo
                    float* y, int N, int I, int O, void* stream);
 int step_dense_bwd(const float* dy, const float* x, const float* w, int w_transposed,
                    float* dx, float* dw, float* db, int N, int I, int O, void* stream);
+/* The classifier's inference head in one launch: feat = avg_pool(x) (N,C), out = feat W^T + b (N,O), softmaxed when
+ * `softmax` (classifier.py:81-87: avg_pool2d, fcn, F.softmax; the real_and_synth variant returns the logits).
+ * Bit-identical to step_pool_fwd + step_dense_fwd (+ step_softmax_fwd), which the autograd path keeps.     */
+int step_head_fwd(const float* x, const float* w, const float* b, int w_transposed, int softmax,
+                  float* feat, float* out, int N, int C, int inner, int O, void* stream);
 /* nn.BatchNorm1d on a (N, G) matrix - `data_bn2` of the hybrid head,
  * classifier_hybrid/net/classifier.py:46,83.  Emits mean/invstd (batch or running).        */
 int step_bn_rows_fwd(const float* x, const float* gamma, const float* beta,

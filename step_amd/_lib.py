@@ -67,6 +67,7 @@ SIGNATURES = {
     "step_aff_normalize": (I, [P, P, I, I, I, P]),
     "step_pool_fwd": (I, [P, P, I, I, I, P]),
     "step_pool_bwd": (I, [P, P, I, I, I, P]),
+    "step_head_fwd": (I, [P, P, P, I, I, P, P, I, I, I, I, P]),
     "step_dense_fwd": (I, [P, P, P, I, P, I, I, I, P]),
     "step_dense_bwd": (I, [P, P, P, I, P, P, P, I, I, I, P]),
     "step_bn_rows_fwd": (I, [P, P, P, P, P, I, F, F, P, P, P, I, I, P]),

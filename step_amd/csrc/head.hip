@@ -32,6 +32,53 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const float* __restrict__
     if (lane == 0) feat[row] = s / (float)inner;
 }
 
+// Inference head in ONE launch: pooling, the 1x1 `fcn` and (real_only) the softmax of classifier.py:81-87 for one
+// sequence per block.  Every sum runs in the order of pool_fwd_kernel / dense_fwd_kernel / softmax_fwd_kernel, so the
+// results are bit-identical to the three separate launches the autograd path keeps.
+__global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                       const float* __restrict__ b, int wt, int softmax,
+                                                       float* __restrict__ feat, float* __restrict__ out,
+                                                       int C, int inner, int O) {
+    extern __shared__ float sh[];                       // [C] pooled feature, then [O] logits
+    float* logit = sh + C;
+    const int n = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n4 = inner >> 2;
+    for (int c = wave; c < C; c += 4) {
+        const float* src = x + ((size_t)n * C + c) * inner;
+        float s = 0.f;
+        for (int i = lane; i < n4; i += 64) {
+            const float4 v = *reinterpret_cast<const float4*>(src + i * 4);
+            s += (v.x + v.y) + (v.z + v.w);
+        }
+        for (int i = n4 * 4 + lane; i < inner; i += 64) s += src[i];
+        s = wave_sum(s);
+        if (lane == 0) {
+            const float f = s / (float)inner;
+            sh[c] = f;
+            feat[(size_t)n * C + c] = f;
+        }
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < O; o += 256) {
+        float s = b ? b[o] : 0.f;
+        if (wt) for (int i = 0; i < C; ++i) s = fmaf(sh[i], w[(size_t)i * O + o], s);
+        else    for (int i = 0; i < C; ++i) s = fmaf(sh[i], w[(size_t)o * C + i], s);
+        logit[o] = s;
+        if (!softmax) out[(size_t)n * O + o] = s;
+    }
+    if (!softmax) return;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float m = logit[0];
+        for (int o = 1; o < O; ++o) m = fmaxf(m, logit[o]);
+        float s = 0.f;
+        for (int o = 0; o < O; ++o) s += expf(logit[o] - m);
+        const float inv = 1.f / s;
+        for (int o = 0; o < O; ++o) out[(size_t)n * O + o] = expf(logit[o] - m) * inv;
+    }
+}
+
 // one float4 per thread (inner % 4 == 0: a float4 never straddles two (n, c) rows), written once: non-temporal
 __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__ dfeat,
                                                        float* __restrict__ dx, size_t total4,
@@ -212,6 +259,15 @@ extern "C" int step_pool_fwd(const float* x, float* feat, int N, int C, int inne
     hipLaunchKernelGGL(pool_fwd_kernel, dim3(step::ceil_div(NC, 4)), dim3(256), 0, (hipStream_t)stream,
                        x, feat, NC, inner);
     return step::check_launch("step_pool_fwd");
+}
+
+extern "C" int step_head_fwd(const float* x, const float* w, const float* b, int w_transposed, int softmax,
+                             float* feat, float* out, int N, int C, int inner, int O, void* stream) {
+    STEP_REQUIRE(x && w && feat && out && N > 0 && C > 0 && C <= 1024 && O > 0 && O <= 1024 && inner > 0,
+                 "step_head_fwd: bad args N=%d C=%d inner=%d O=%d", N, C, inner, O);
+    hipLaunchKernelGGL(head_fwd_kernel, dim3(N), dim3(256), (C + O) * sizeof(float), (hipStream_t)stream, x, w, b,
+                       w_transposed, softmax, feat, out, C, inner, O);
+    return step::check_launch("step_head_fwd");
 }
 
 extern "C" int step_pool_bwd(const float* dfeat, float* dx, int N, int C, int inner, void* stream) {

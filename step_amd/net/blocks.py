@@ -58,6 +58,16 @@ class _StBlock(nn.Module):
         self._geom = (in_channels, out_channels, kernel_size[0], stride)
         self.a_nnz_max = 16
         self.mfma_dtype = "f32"             # "bf16": step_amd.set_mfma_dtype(model, "bf16")
+        self._infer_cache = {}              # packed temporal weights, eval-mode BN coefficients (ops.cached)
+
+    def invalidate_caches(self):
+        """Drop the inference caches.  They follow in-place parameter updates by themselves (tensor versions); call this
+        after writing parameters through `.data`, which bumps no version."""
+        self._infer_cache.clear()
+
+    def train(self, mode=True):
+        self._infer_cache.clear()           # (weights_init writes through .data before training starts)
+        return super().train(mode)
 
     @property
     def graph_conv(self):
@@ -84,6 +94,7 @@ class _StBlock(nn.Module):
                          self.tcn[0], self.tcn[3], bnr, data_bn,
                          bf16={"bf16": True, "f32_split": "split", "f32_split_wgrad": "split_wgrad",
                                "f32_split_gcn": "split_gcn"}.get(self.mfma_dtype, False))
+        spec.cache = self._infer_cache
         g = self.graph_conv.conv
         params = []
         if data_bn is not None:
@@ -103,6 +114,7 @@ class _StBlock(nn.Module):
         bnr = self.residual[1] if self._res_kind == "conv" else None
         spec = BlockSpec(ci, co, kt, stride, self._res_kind, self.transposed, self.a_nnz_max,
                          self.tcn[0], self.tcn[3], bnr, None)
+        spec.cache = self._infer_cache
         g = self.graph_conv.conv
         rw = rb = None
         if bnr is not None:

@@ -49,6 +49,24 @@ class _ClassifierBase(nn.Module):
                 b.gcn.a_nnz_max = nnz
             self._nnz_key = key
 
+    def _a_eff(self):
+        """[A * importance] per block (classifier.py:78); in a no-grad eval forward the products are cached per
+        version of A and of the importance parameters"""
+        if self.training or torch.is_grad_enabled():
+            return [self.A * imp for imp in self.edge_importance]
+        from ..ops import tensor_key
+        key = tensor_key(self.A, *[imp for imp in self.edge_importance if isinstance(imp, torch.Tensor)])
+        ent = getattr(self, "_a_eff_cache", None)
+        if ent is None or ent[0] != key:
+            with torch.no_grad():
+                ent = (key, [(self.A * imp).contiguous() for imp in self.edge_importance])
+            self._a_eff_cache = ent
+        return ent[1]
+
+    def train(self, mode=True):
+        self._a_eff_cache = None
+        return super().train(mode)
+
     def _stack(self, x):
         N, C, T, V, M = x.size()
         if M != 1:
@@ -61,8 +79,8 @@ class _ClassifierBase(nn.Module):
         x = x.float().contiguous()
         data_bn = getattr(self, self.DATA_BN)
         self._sync_nnz()
-        for i, (gcn, importance) in enumerate(zip(self.st_gcn_networks, self.edge_importance)):
-            x, _ = gcn(x, self.A * importance, data_bn if i == 0 else None)
+        for i, (gcn, a_eff) in enumerate(zip(self.st_gcn_networks, self._a_eff())):
+            x, _ = gcn(x, a_eff, data_bn if i == 0 else None)
         return x, (N, M)
 
     def _pooled(self, x):
@@ -84,6 +102,12 @@ class Classifier(_ClassifierBase):
     RETURNS_SOFTMAX = True
 
     def forward(self, x):
+        if not self.training and not torch.is_grad_enabled() and x.size(4) == 1:
+            # inference: pooling, fcn and softmax in one launch (same sums, bit-identical to the path below)
+            from ..ops import head_inference
+            h, _ = self._stack(x)
+            out, pooled = head_inference(h, self.fcn.weight.detach(), self.fcn.bias.detach(), self.RETURNS_SOFTMAX)
+            return out, pooled.view(pooled.size(0), -1, 1, 1).squeeze()
         pooled = self._pooled(x)
         f = pooled.view(pooled.size(0), -1, 1, 1).squeeze()
         logits = DenseFn.apply(pooled, self.fcn.weight, self.fcn.bias, False)

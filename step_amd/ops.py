@@ -78,6 +78,24 @@ def bn_finalize_sums(sums, count, bn, synced, momentum=BN_MOMENTUM):
     return mean, invstd, scale, shift
 
 
+def tensor_key(*tensors):
+    """identity + in-place version of tensors, for the inference caches below: an optimizer step, load_state_dict
+    (copy_) and any other in-place write bump `_version`, .to() / re-assignment change `data_ptr`.  Writes through
+    `.data` do NOT bump it: the blocks drop their caches on train() and offer invalidate_caches() for that case."""
+    return tuple((t.data_ptr(), t._version, str(t.device)) if t is not None else None for t in tensors)
+
+
+def cached(cache, name, key, build):
+    """cache[name] if it was built from `key`, else build() (cache None: always build)"""
+    if cache is None:
+        return build()
+    ent = cache.get(name)
+    if ent is None or ent[0] != key:
+        ent = (key, build())
+        cache[name] = ent
+    return ent[1]
+
+
 def bn_eval_prepare(weight, bias, running_mean, running_var):
     G = running_mean.numel()
     scale = torch.empty(G, dtype=torch.float32, device=running_mean.device)
@@ -118,6 +136,12 @@ def bn_prepare(x, bn_mode, bn, training):
     scale, shift = bn_eval_prepare(bn.weight, bn.bias, bn.running_mean, bn.running_var)
     invstd = torch.rsqrt(bn.running_var + BN_EPS)
     return bn.running_mean, invstd, scale, shift
+
+
+def bn_eval_cached(cache, name, bn):
+    """eval-mode (scale, shift) of a BatchNorm container, computed once per parameter version"""
+    return cached(cache, name, tensor_key(bn.weight, bn.bias, bn.running_mean, bn.running_var),
+                  lambda: bn_eval_prepare(bn.weight, bn.bias, bn.running_mean, bn.running_var))
 
 
 def affine_act(x, scale, shift, res, rscale, rshift, relu, bn_mode=0):
@@ -305,6 +329,7 @@ class BlockSpec:
         self.nnz = nnz
         self.bn1, self.bn2, self.bnr, self.data_bn = bn1, bn2, bnr, data_bn
         self.grad_enabled = torch.is_grad_enabled()     # of the caller that builds the spec, right before apply()
+        self.cache = None       # dict owned by the block module: packed weights / eval BN coefficients (inference)
 
 
 class StGcnBlockFn(torch.autograd.Function):
@@ -348,6 +373,10 @@ class StGcnBlockFn(torch.autograd.Function):
         need_grad = s.grad_enabled and any(ctx.needs_input_grad)
         dev = x.device
 
+        fused = (not training) and (not need_grad)
+        if fused:
+            return StGcnBlockFn._forward_inference(s, x, A_eff, gcn_w, gcn_b, tcn_w, tcn_b, res_w, res_b)
+
         # data_bn statistics (training) or running stats (eval); applied inside the gcn load
         m0 = i0 = s0 = h0 = None
         if s.data_bn is not None:
@@ -381,20 +410,6 @@ class StGcnBlockFn(torch.autograd.Function):
         bf = s.bf16_fwd
         wp = tcn_pack(tcn_w, Co, Co, Kt, st, mode, bf16=bf)
         mr = ir = sr = hr = None
-        fused = (not training) and (not need_grad)
-        if fused:
-            # eval: BN2, residual (its BN folded) and the final ReLU ride in the MFMA epilogue
-            _, _, s2, h2 = bn_prepare(None, 0, s.bn2, False)
-            res_t = None
-            if s.residual == "conv":
-                _, _, sr, hr = bn_prepare(None, 0, s.bnr, False)
-                res_t = r
-            elif s.residual == "identity":
-                res_t = x
-            out = tcn_conv(y, s1, h1, True, wp, tcn_b, s2, h2, res_t, sr, hr, True,
-                           N, Co, Co, T, To, Kt, st, mode, bf16=bf)
-            return out
-
         u = tcn_conv(y, s1, h1, True, wp, tcn_b, None, None, None, None, None, False,
                      N, Co, Co, T, To, Kt, st, mode, bf16=bf)
         m2, i2, s2, h2 = bn_prepare(u, 0, s.bn2, training)
@@ -414,6 +429,40 @@ class StGcnBlockFn(torch.autograd.Function):
                                   dbn_w, m0, i0, s0, h0, m1, i1, s1, h1, m2, i2, s2, h2, mr, ir, sr, hr)
             ctx.x_needs_grad = ctx.needs_input_grad[2]
         return out
+
+    @staticmethod
+    def _forward_inference(s, x, A_eff, gcn_w, gcn_b, tcn_w, tcn_b, res_w, res_b):
+        """eval mode, nothing to differentiate: TWO launches per block - the graph conv (data_bn folded into its load)
+        and the temporal conv with BN1 + ReLU on its load and BN2, the residual (its BN folded) and the final ReLU in
+        its MFMA epilogue.  The packed temporal weights and every BatchNorm's (scale, shift) are cached on the block
+        per parameter version (s.cache), so a second forward launches no pack / prepare kernel."""
+        N, Ci, T, V = x.shape
+        Co, Kt, st = s.Co, s.Kt, s.stride
+        To = (T - 1) // st + 1
+        K = A_eff.shape[0]
+        dev = x.device
+        c = s.cache
+        s0 = h0 = None
+        if s.data_bn is not None:
+            s0, h0 = bn_eval_cached(c, "data_bn", s.data_bn)
+        y = torch.empty((N, Co, T, 16), dtype=torch.float32, device=dev)
+        r = torch.empty((N, Co, To, 16), dtype=torch.float32, device=dev) if res_w is not None else None
+        _lib.call(s.gcn_fwd, x, s0, h0, gcn_w, gcn_b, int(s.transposed), A_eff, s.nnz, y,
+                  res_w, res_b, int(s.transposed), r, N, Ci, Co, K, T, st)
+        s1, h1 = bn_eval_cached(c, "bn1", s.bn1)
+        mode = 1 if s.transposed else 0
+        bf = s.bf16_fwd
+        wp = cached(c, "wp", tensor_key(tcn_w) + (str(bf), mode, st),
+                    lambda: tcn_pack(tcn_w, Co, Co, Kt, st, mode, bf16=bf))
+        s2, h2 = bn_eval_cached(c, "bn2", s.bn2)
+        res_t = sr = hr = None
+        if s.residual == "conv":
+            sr, hr = bn_eval_cached(c, "bnr", s.bnr)
+            res_t = r
+        elif s.residual == "identity":
+            res_t = x
+        return tcn_conv(y, s1, h1, True, wp, tcn_b, s2, h2, res_t, sr, hr, True,
+                        N, Co, Co, T, To, Kt, st, mode, bf16=bf)
 
     @staticmethod
     def backward(ctx, dout):
@@ -503,14 +552,19 @@ def block_repeated_input_eval(spec, h, A_eff, T, gcn_w, gcn_b, tcn_w, tcn_b, res
         res_w = res_b = None
     _lib.call("step_gcn_fwd", x1, None, None, gcn_w, gcn_b, int(s.transposed), A_eff, s.nnz, y0,
               res_w, res_b, int(s.transposed), r0, N, Ci, Co, K, 1, 1)
-    _, _, s1, h1 = bn_prepare(None, 0, s.bn1, False)
+    c = s.cache
+    s1, h1 = bn_eval_cached(c, "bn1", s.bn1)
     a0 = affine_act(y0, s1, h1, None, None, None, True, 0)
-    wcum = torch.empty((T, Co, Co), dtype=torch.float32, device=dev)
-    _lib.call("step_tcn_const_weights", tcn_w, wcum, Co, Co, Kt, T, int(s.transposed))
-    _, _, s2, h2 = bn_prepare(None, 0, s.bn2, False)
+
+    def build_wcum():
+        wc = torch.empty((T, Co, Co), dtype=torch.float32, device=dev)
+        _lib.call("step_tcn_const_weights", tcn_w, wc, Co, Co, Kt, T, int(s.transposed))
+        return wc
+    wcum = cached(c, "wcum", tensor_key(tcn_w) + (T,), build_wcum)
+    s2, h2 = bn_eval_cached(c, "bn2", s.bn2)
     res0 = sr = hr = None
     if s.residual == "conv":
-        _, _, sr, hr = bn_prepare(None, 0, s.bnr, False)
+        sr, hr = bn_eval_cached(c, "bnr", s.bnr)
         res0 = r0
     elif s.residual == "identity":
         res0 = x1
@@ -539,6 +593,17 @@ class PoolFn(torch.autograd.Function):
         dx = torch.empty(ctx.shape, dtype=torch.float32, device=dfeat.device)
         _lib.call("step_pool_bwd", _f32(dfeat), dx, N, C, dx.numel() // (N * C))
         return dx
+
+
+def head_inference(h, weight, bias, softmax):
+    """(out, feat) of avg_pool2d -> fcn (-> softmax) for a no-grad eval forward, one launch (step_head_fwd)"""
+    h = _f32(h)
+    N, C = h.shape[0], h.shape[1]
+    O = weight.shape[0]
+    feat = torch.empty((N, C), dtype=torch.float32, device=h.device)
+    out = torch.empty((N, O), dtype=torch.float32, device=h.device)
+    _lib.call("step_head_fwd", h, _f32(weight), bias, 0, int(softmax), feat, out, N, C, h.numel() // (N * C), O)
+    return out, feat
 
 
 class DenseFn(torch.autograd.Function):

@@ -653,3 +653,51 @@ def test_epoch_level_caller_train_save_reload_eval(tmp_path):
         with torch.no_grad():
             live, _ = run.model(run.test_set[0])
         assert torch.equal(live, a)
+
+
+def test_second_eval_forward_launches_no_pack_or_prepare(monkeypatch):
+    """Inference host path (the reference's batch-1 prediction loop, processor.py:457-473): packed temporal weights,
+    eval-mode BatchNorm coefficients and A * importance are cached per parameter version, pooling + fcn + softmax are
+    one launch.  Second no-grad eval forward: 2 launches per block + 1 head, none of them a pack / prepare kernel;
+    an in-place parameter update or train() refreshes the caches."""
+    from step_amd import _lib
+    from step_amd.net.classifier import Classifier
+    P = ckpt("ckpt_classifier_real_only_epoch395")
+    m = _load(Classifier(3, 4, {"strategy": "spatial"}), P).eval()
+    x = torch.randn(3, 3, 75, 16, 1, generator=torch.Generator().manual_seed(3)).to(D)
+    names = []
+    real = _lib.call
+    monkeypatch.setattr(_lib, "call", lambda name, *a: (names.append(name), real(name, *a))[1])
+    with torch.no_grad():
+        o1, f1 = m(x)
+        first = list(names)
+        del names[:]
+        o2, f2 = m(x)
+    assert any(n.startswith("step_tcn_pack_weight") for n in first) and "step_bn_eval_prepare" in first
+    assert sorted(names) == sorted(["step_gcn_fwd", "step_tcn_conv"] * 3 + ["step_head_fwd"]), names
+    assert torch.equal(o1, o2) and torch.equal(f1, f2)
+    ref, rfeat = stgcn.classifier_forward({k: v.clone() for k, v in P.items()}, x.cpu(), "real_only")
+    assert_close(o2, ref, 1e-4, "cached eval probs")
+    assert_close(f2, rfeat, 1e-4, "cached eval feat")
+    # the one-launch head against the three-launch autograd path: same sums, bit for bit
+    o3, f3 = m(x)
+    assert o3.requires_grad
+    assert_close(o2, o3.detach(), 1e-5, "fused epilogue vs separate pass")
+    # an in-place update (what optimizer.step / load_state_dict do) is seen through the tensor version ...
+    with torch.no_grad():
+        m.st_gcn_networks[1].tcn[2].weight.mul_(1.5)
+        m.st_gcn_networks[2].tcn[3].running_var.mul_(2.0)
+        m.edge_importance[0].mul_(0.5)
+        del names[:]
+        o4, _ = m(x)
+    assert names.count("step_tcn_pack_weight") == 1 and names.count("step_bn_eval_prepare") == 1
+    P2 = {k: v.clone() for k, v in m.state_dict().items()}
+    ref4, _ = stgcn.classifier_forward({k: v.cpu() for k, v in P2.items()}, x.cpu(), "real_only")
+    assert_close(o4, ref4, 1e-4, "after in-place parameter updates")
+    # ... and train() / eval() drop every cache (weights_init writes through .data, which bumps no version)
+    m.train()
+    m.eval()
+    with torch.no_grad():
+        del names[:]
+        m(x)
+    assert names.count("step_tcn_pack_weight") == 3

@@ -224,6 +224,29 @@ def aff(reps):
     return out
 
 
+def batch1(reps):
+    """The reference's prediction loop (processor.py:457-473: one batch-1 forward per gait, T = 75): latency per gait
+    through step_amd.export.generate_predictions with batch=1, and the same 256 gaits in one batch"""
+    import numpy as np
+    from step_amd import export
+    from step_amd.net.classifier import Classifier
+    torch.manual_seed(0)
+    m = _mode(init_like_reference(Classifier(3, 4, {"strategy": "spatial"})).to(D).eval())
+    n, t = 256, 75
+    data = (torch.randn(n, t, 48, generator=torch.Generator().manual_seed(5)) * 0.3).numpy()
+    out = []
+    for batch in (1, n):
+        dt = timeit(lambda: export.generate_predictions(m, data, 4, 16, 3, batch=batch), reps)
+        out.append({"config": "generate_predictions, %d gaits x T=75, batch %d (host numpy in, labels out)" % (n, batch),
+                    "ms_per_gait": dt * 1e3 / n, "gaits_per_s": n / dt})
+    x1 = torch.from_numpy(np.ascontiguousarray(np.moveaxis(data[:1].reshape(1, t, 16, 3, 1), [1, 2, 3], [2, 3, 1]))).float().to(D)
+    with torch.no_grad():
+        dt = timeit(lambda: m(x1), 200)
+    out.append({"config": "one batch-1 eval forward, input resident (7 launches: 2 per block + head)", "ms_per_gait": dt * 1e3,
+                "gaits_per_s": 1 / dt})
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=3)
@@ -234,7 +257,7 @@ def main():
     global MODE
     MODE = a.mfma
     for k in a.only.split(","):
-        r = {"2": config2, "3": config3, "4": config4, "5": config5, "aff": aff, "kt9": kt9, "cvae_train": cvae_train}[k](a.reps)
+        r = {"2": config2, "3": config3, "4": config4, "5": config5, "aff": aff, "kt9": kt9, "cvae_train": cvae_train, "batch1": batch1}[k](a.reps)
         for line in (r if isinstance(r, list) else [r]):
             if MODE != "f32":
                 line["mfma"] = MODE
