@@ -344,6 +344,21 @@ int step_bn_rows_fwd(const float* x, const float* gamma, const float* beta,
 int step_bn_rows_bwd(const float* dy, const float* x, const float* mean, const float* invstd,
                      const float* gamma, int training, float* dx, float* dgamma, float* dbeta,
                      int N, int G, void* stream);
+/* The same BatchNorm1d in train mode with its batch taken over SEVERAL GPUs (synchronised BatchNorm, as
+ * step_bn_train_stats / _finalize do for the 4-D layers; data_bn2, classifier_hybrid/net/classifier.py:46,83):
+ *   _stats     sums[2g] = SUM x, sums[2g+1] = SUM x^2 over this rank's N rows (2G doubles of a 2G+1 buffer; the host
+ *              writes its row count into slot 2G and all-reduces the buffer);
+ *   _apply     mean / biased variance from the combined buffer (count read from slot 2G), running-stat update, y;
+ *   _bwd_sums  sums[2g] = SUM dy, sums[2g+1] = SUM dy * xhat (this rank), dgamma / dbeta from them (nullable);
+ *   _bwd_apply dx = gamma * invstd * (dy - S1/M - xhat * S2/M) with the combined sums and M = slot 2G.       */
+int step_bn_rows_stats(const float* x, double* sums, int N, int G, void* stream);
+int step_bn_rows_apply(const float* x, const double* sums, const float* gamma, const float* beta,
+                       float* running_mean, float* running_var, float momentum, float eps, float* y,
+                       float* mean, float* invstd, int N, int G, void* stream);
+int step_bn_rows_bwd_sums(const float* dy, const float* x, const float* mean, const float* invstd,
+                          double* sums, float* dgamma, float* dbeta, int N, int G, void* stream);
+int step_bn_rows_bwd_apply(const float* dy, const float* x, const float* mean, const float* invstd,
+                           const float* gamma, const double* sums, float* dx, int N, int G, void* stream);
 /* F.softmax(x, dim=1) classifier.py:87 and its backward */
 int step_softmax_fwd(const float* x, float* y, int N, int O, void* stream);
 int step_softmax_bwd(const float* dy, const float* y, float* dx, int N, int O, void* stream);

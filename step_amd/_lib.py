@@ -72,6 +72,10 @@ SIGNATURES = {
     "step_dense_bwd": (I, [P, P, P, I, P, P, P, I, I, I, P]),
     "step_bn_rows_fwd": (I, [P, P, P, P, P, I, F, F, P, P, P, I, I, P]),
     "step_bn_rows_bwd": (I, [P, P, P, P, P, I, P, P, P, I, I, P]),
+    "step_bn_rows_stats": (I, [P, P, I, I, P]),
+    "step_bn_rows_apply": (I, [P, P, P, P, P, P, F, F, P, P, P, I, I, P]),
+    "step_bn_rows_bwd_sums": (I, [P, P, P, P, P, P, P, I, I, P]),
+    "step_bn_rows_bwd_apply": (I, [P, P, P, P, P, P, P, I, I, P]),
     "step_softmax_fwd": (I, [P, P, I, I, P]),
     "step_softmax_bwd": (I, [P, P, P, I, I, P]),
 }

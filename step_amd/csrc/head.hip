@@ -230,7 +230,108 @@ __global__ __launch_bounds__(64) void bn_rows_bwd_kernel(const float* __restrict
     }
 }
 
+// ---- the same BatchNorm1d with its batch statistics taken over SEVERAL ranks (synchronised BatchNorm): the sums
+// leave as doubles (exact products of fp32 inputs, so the one-pass variance keeps a near-constant column), the
+// host all-reduces [sums, count], and the apply kernels take the combined buffer (count in slot 2G).
+__global__ __launch_bounds__(64) void bn_rows_stats_kernel(const float* __restrict__ x, double* __restrict__ sums,
+                                                           int N, int G) {
+    const int g = blockIdx.x, lane = threadIdx.x;
+    double s = 0.0, ss = 0.0;
+    for (int n = lane; n < N; n += 64) { const double v = (double)x[(size_t)n * G + g]; s += v; ss += v * v; }
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); ss += __shfl_xor(ss, o, 64); }
+    if (lane == 0) { sums[2 * g] = s; sums[2 * g + 1] = ss; }
+}
+
+__global__ __launch_bounds__(64) void bn_rows_apply_kernel(const float* __restrict__ x, const double* __restrict__ sums,
+                                                           const float* gamma, const float* beta, float* running_mean,
+                                                           float* running_var, float momentum, float eps,
+                                                           float* __restrict__ y, float* mean_out, float* invstd_out,
+                                                           int N, int G) {
+    const int g = blockIdx.x, lane = threadIdx.x;
+    const double cnt = sums[2 * G];
+    const double md = sums[2 * g] / cnt;
+    double vard = sums[2 * g + 1] / cnt - md * md;
+    vard = vard > 0.0 ? vard : 0.0;
+    const float m = (float)md, inv = (float)(1.0 / sqrt(vard + (double)eps));
+    if (lane == 0) {
+        mean_out[g] = m; invstd_out[g] = inv;
+        if (running_mean) {
+            const double unb = cnt > 1.0 ? vard * cnt / (cnt - 1.0) : vard;
+            running_mean[g] = (float)((1.0 - momentum) * running_mean[g] + momentum * md);
+            running_var[g] = (float)((1.0 - momentum) * running_var[g] + momentum * unb);
+        }
+    }
+    const float sc = (gamma ? gamma[g] : 1.f) * inv, sh = (beta ? beta[g] : 0.f) - m * sc;
+    for (int n = lane; n < N; n += 64) y[(size_t)n * G + g] = x[(size_t)n * G + g] * sc + sh;
+}
+
+// sums[2g] = SUM dy, sums[2g+1] = SUM dy * xhat over this rank's rows (doubles); dgamma / dbeta from them
+__global__ __launch_bounds__(64) void bn_rows_bwd_sums_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                              const float* mean, const float* invstd,
+                                                              double* __restrict__ sums, float* dgamma, float* dbeta,
+                                                              int N, int G) {
+    const int g = blockIdx.x, lane = threadIdx.x;
+    const float m = mean[g], inv = invstd[g];
+    double s1 = 0.0, s2 = 0.0;
+    for (int n = lane; n < N; n += 64) {
+        const float d = dy[(size_t)n * G + g];
+        s1 += (double)d; s2 += (double)(d * (x[(size_t)n * G + g] - m) * inv);
+    }
+    for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+    if (lane == 0) {
+        sums[2 * g] = s1; sums[2 * g + 1] = s2;
+        if (dgamma) dgamma[g] = (float)s2;
+        if (dbeta) dbeta[g] = (float)s1;
+    }
+}
+
+__global__ __launch_bounds__(64) void bn_rows_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                               const float* mean, const float* invstd, const float* gamma,
+                                                               const double* __restrict__ sums, float* __restrict__ dx,
+                                                               int N, int G) {
+    const int g = blockIdx.x, lane = threadIdx.x;
+    const float m = mean[g], inv = invstd[g], ga = gamma ? gamma[g] : 1.f;
+    const double cnt = sums[2 * G];
+    const float a = (float)(sums[2 * g] / cnt), b = (float)(sums[2 * g + 1] / cnt);
+    for (int n = lane; n < N; n += 64) {
+        const float d = dy[(size_t)n * G + g];
+        dx[(size_t)n * G + g] = ga * inv * (d - a - (x[(size_t)n * G + g] - m) * inv * b);
+    }
+}
+
 }  // namespace
+
+extern "C" int step_bn_rows_stats(const float* x, double* sums, int N, int G, void* stream) {
+    STEP_REQUIRE(x && sums && N > 0 && G > 0, "step_bn_rows_stats: bad args");
+    hipLaunchKernelGGL(bn_rows_stats_kernel, dim3(G), dim3(64), 0, (hipStream_t)stream, x, sums, N, G);
+    return step::check_launch("step_bn_rows_stats");
+}
+
+extern "C" int step_bn_rows_apply(const float* x, const double* sums, const float* gamma, const float* beta,
+                                  float* running_mean, float* running_var, float momentum, float eps, float* y,
+                                  float* mean, float* invstd, int N, int G, void* stream) {
+    STEP_REQUIRE(x && sums && y && mean && invstd && N > 0 && G > 0, "step_bn_rows_apply: bad args");
+    STEP_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "step_bn_rows_apply: running stats come in pairs");
+    hipLaunchKernelGGL(bn_rows_apply_kernel, dim3(G), dim3(64), 0, (hipStream_t)stream, x, sums, gamma, beta,
+                       running_mean, running_var, momentum, eps, y, mean, invstd, N, G);
+    return step::check_launch("step_bn_rows_apply");
+}
+
+extern "C" int step_bn_rows_bwd_sums(const float* dy, const float* x, const float* mean, const float* invstd,
+                                     double* sums, float* dgamma, float* dbeta, int N, int G, void* stream) {
+    STEP_REQUIRE(dy && x && mean && invstd && sums && N > 0 && G > 0, "step_bn_rows_bwd_sums: bad args");
+    hipLaunchKernelGGL(bn_rows_bwd_sums_kernel, dim3(G), dim3(64), 0, (hipStream_t)stream, dy, x, mean, invstd, sums,
+                       dgamma, dbeta, N, G);
+    return step::check_launch("step_bn_rows_bwd_sums");
+}
+
+extern "C" int step_bn_rows_bwd_apply(const float* dy, const float* x, const float* mean, const float* invstd,
+                                      const float* gamma, const double* sums, float* dx, int N, int G, void* stream) {
+    STEP_REQUIRE(dy && x && mean && invstd && sums && dx && N > 0 && G > 0, "step_bn_rows_bwd_apply: bad args");
+    hipLaunchKernelGGL(bn_rows_bwd_apply_kernel, dim3(G), dim3(64), 0, (hipStream_t)stream, dy, x, mean, invstd, gamma,
+                       sums, dx, N, G);
+    return step::check_launch("step_bn_rows_bwd_apply");
+}
 
 extern "C" int step_bn_rows_fwd(const float* x, const float* gamma, const float* beta,
                                 float* running_mean, float* running_var, int training,

@@ -683,10 +683,18 @@ class BnRowsFn(torch.autograd.Function):
         y = torch.empty_like(x)
         mean = torch.empty(G, dtype=torch.float32, device=x.device)
         invstd = torch.empty_like(mean)
-        if training and _sync_world() > 1:
-            raise _lib.StepHipError("synchronised BatchNorm does not cover the hybrid head's BatchNorm1d on (N, G) rows")
-        _lib.call("step_bn_rows_fwd", x, weight, bias, bn.running_mean, bn.running_var, int(training),
-                  BN_MOMENTUM, BN_EPS, y, mean, invstd, N, G)
+        ctx.synced = bool(training and _sync_world() > 1)
+        if ctx.synced:
+            # synchronised BatchNorm: [SUM x, SUM x^2, row count] over all ranks in one fp64 all-reduce
+            sums = torch.empty(2 * G + 1, dtype=torch.float64, device=x.device)
+            _lib.call("step_bn_rows_stats", x, sums, N, G)
+            sums[2 * G] = float(N)
+            _sync_sums(sums)
+            _lib.call("step_bn_rows_apply", x, sums, weight, bias, bn.running_mean, bn.running_var, BN_MOMENTUM, BN_EPS,
+                      y, mean, invstd, N, G)
+        else:
+            _lib.call("step_bn_rows_fwd", x, weight, bias, bn.running_mean, bn.running_var, int(training),
+                      BN_MOMENTUM, BN_EPS, y, mean, invstd, N, G)
         if training:
             bn.num_batches_tracked += 1
         ctx.training = training
@@ -700,5 +708,14 @@ class BnRowsFn(torch.autograd.Function):
         dx = torch.empty_like(x)
         dg = torch.empty(G, dtype=torch.float32, device=x.device)
         db = torch.empty_like(dg)
+        if ctx.synced:
+            # dgamma / dbeta from this rank's sums (averaged with the other gradients later); dx from the combined ones
+            dy = _f32(dy)
+            sums = torch.empty(2 * G + 1, dtype=torch.float64, device=x.device)
+            _lib.call("step_bn_rows_bwd_sums", dy, x, mean, invstd, sums, dg, db, N, G)
+            sums[2 * G] = float(N)
+            _sync_sums(sums)
+            _lib.call("step_bn_rows_bwd_apply", dy, x, mean, invstd, weight, sums, dx, N, G)
+            return None, None, dx, dg, db
         _lib.call("step_bn_rows_bwd", _f32(dy), x, mean, invstd, weight, int(ctx.training), dx, dg, db, N, G)
         return None, None, dx, dg, db

@@ -132,6 +132,8 @@ def sync_batchnorm(enabled=True, group=None):
     W ranks x N/W sequences compute what the reference's single device computes on N (same normalisation, running
     statistics and gradients).  Per BatchNorm the ranks all-reduce 2*G + 1 doubles (SUM x, SUM x^2, element count)
     in forward and (SUM g, SUM g*x, count) in backward; dgamma / dbeta stay local and are averaged with the other
-    gradients by GradBucket.all_reduce_mean.  The hybrid head's BatchNorm1d on feature rows is not covered."""
+    gradients by GradBucket.all_reduce_mean.  BatchNorms whose inputs exist at the same time share one all-reduce
+    (tcn[0] + residual[1] after the graph conv; tcn[3] + residual[1] in the backward tail); the hybrid head's
+    BatchNorm1d on feature rows (data_bn2) is covered the same way (step_bn_rows_stats / _apply)."""
     from . import ops
     ops.set_sync_bn(enabled, group)

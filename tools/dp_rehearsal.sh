@@ -1,6 +1,19 @@
 #!/bin/bash
-# 2-rank rehearsal of bench.py's data-parallel path on a 1-GPU box (gloo, both ranks on cuda:0).
-# The real multi-GPU run uses RCCL: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N
-export STEP_DIST_BACKEND=gloo STEP_LOCAL_DEVICE=0 HSA_ENABLE_IPC_MODE_LEGACY=0 PYTHONFAULTHANDLER=1
-exec python -u -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 \
-    bench.py --gpus 2 --steps 2 --warmup 1 --batch 256 --no-cpu --no-kernels "$@"
+# Data-parallel REHEARSAL on the one-GPU box: 2 ranks share the card, collectives over gloo through host memory
+# (RCCL refuses two ranks on one device) - not a scaling number.  What it puts on record: the step time of the
+# configs[2]-sized shard (per-GPU batch 512, bf16 MFMA operands) alone, as 2 ranks with the gradient bucket only,
+# and as 2 ranks with synchronised BatchNorm (7 + 6 small fp64 collectives more per step).
+set -e
+mkdir -p gpurun_out
+OUT=gpurun_out/dp_rehearsal.jsonl
+: > $OUT
+COMMON="--batch 512 --steps 10 --warmup 3 --no-cpu --no-kernels --no-infer --no-bf16 --mfma bf16"
+timeout -k 10 300 python bench.py --gpus 1 $COMMON | grep "^{" >> $OUT
+timeout -k 10 300 python bench.py --gpus 2 $COMMON | grep "^{" >> $OUT
+timeout -k 10 300 python bench.py --gpus 2 $COMMON --sync-bn | grep "^{" >> $OUT
+python - <<'PY'
+import json
+for l in open("gpurun_out/dp_rehearsal.jsonl"):
+    d = json.loads(l)
+    print(d["n_gpus"], d["config"]["parallelism"], d["ms_per_step"], "ms/step", d["value"], "seq/s", "rehearsal" if d.get("rehearsal") else "")
+PY
