@@ -240,6 +240,17 @@ int step_tcn_conv(const float* in, const float* in_scale, const float* in_shift,
                   int N, int Ci, int Co, int Tin, int Tout, int Kt, int stride, int pack_mode,
                   void* stream);
 
+/* step_tcn_conv for a TRAIN-mode block (pack_mode 0 / 1, no fused epilogue): the raw conv output u (+ bias) and, from
+ * the kernel's epilogue, sums = [SUM u, SUM u^2] per output channel over (N, Tout, V) (2*Co doubles) for the batch
+ * statistics of tcn[3] (nn.BatchNorm2d, classifier.py:163), in the layout step_bn_train_finalize takes: u is not read
+ * again for statistics.  Per-block fp32 partials (one sequence, at most 40 frames), then fp64, fixed summation
+ * order: bit-reproducible.  ws: step_tcn_conv_stats_ws_bytes(N, Co, Tout) bytes.                             */
+size_t step_tcn_conv_stats_ws_bytes(int N, int Co, int Tout);
+int step_tcn_conv_stats(const float* in, const float* in_scale, const float* in_shift, int in_relu,
+                        const float* wp, const float* bias, float* out,
+                        int N, int Ci, int Co, int Tin, int Tout, int Kt, int stride, int pack_mode,
+                        double* sums, void* ws, size_t ws_bytes, void* stream);
+
 /* Temporal conv of a frame-independent input: the decoder repeats its latent vector over T and V before the
  * first st_gctn block (generator_cvae/net/CVAE_stgcn.py Decoder.forward, `z.repeat([1, 1, T, V])`), so that
  * block's conv is one Co x Ci matrix per output frame (the taps inside the sequence there), stride 1:

@@ -44,6 +44,8 @@ struct TcnParams {
     int in_relu, out_relu;
     int N, Cin, Cout, Cpad, PH, Tin, Tout, R, padL, nRB;
     int NG;             // groups of 32*MW output rows (wide layers: PH*Cpad > 128); blockIdx.y
+    float* stat_part;   // forward, train mode: per-block [SUM, SUM of squares] of the conv output per channel,
+                        // [blocks.x][Cout][2] floats (NULL: none) - the batch statistics of tcn[3]
 };
 
 template <int NT, int KS, int STRIDE, int MW, int NW>
@@ -226,7 +228,11 @@ __global__ __launch_bounds__(64 * MW * NW, (TcnCfg<NT, KS, STRIDE, MW, NW>::SMEM
         if (p.Cin >= 1) __syncthreads();
     }
 
-    if (!wave_live) return;
+    __shared__ float stat_x[MW * NW][64];                     // per wave: [32 channels][sum | sum of squares]
+    float st1[8], st2[8];                                     // this lane's sums of channels k * 4 + lch
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { st1[k] = 0.f; st2[k] = 0.f; }
+    if (wave_live) {
     // epilogue.  C/D layout: col = lane&31 = (frame parity, joint), row = (r&3) + 8*(r>>2) + 4*(lane>>5) = channel,
     // i.e. a lane holds ONE float of a 64-byte (channel, frame) row, and 4-byte global stores are issue-bound (a
     // wave-instruction costs about the same whatever its width).  So two column tiles at a time go through a
@@ -272,8 +278,65 @@ __global__ __launch_bounds__(64 * MW * NW, (TcnCfg<NT, KS, STRIDE, MW, NW>::SMEM
                     v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
                 }
                 *reinterpret_cast<float4*>(p.out + o) = v;
+                if (p.stat_part) {
+                    st1[k] += (v.x + v.y) + (v.z + v.w);
+                    st2[k] += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+                }
             }
         }
+    }
+    }
+    // batch statistics of the output for the BatchNorm behind it (train-mode forward only; uniform branch): the 16
+    // lanes that share a channel are summed by DPP row rotations, the NW column groups through LDS in a fixed
+    // order, and the block leaves one fp32 partial per channel (at most 40 frames x 16 joints of one sequence);
+    // tcn_stat_fold_kernel carries on in fp64.  Dead waves (frames past the sequence end) contribute zeros.
+    if (p.stat_part) {
+        auto rsum = [](float v) {
+            v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, true));
+            v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, true));
+            v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, true));
+            v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, true));
+            return v;
+        };
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float a = rsum(st1[k]), b = rsum(st2[k]);
+            if ((lane & 15) == 0) {
+                stat_x[wave][(k * 4 + (lane >> 4)) * 2] = a;
+                stat_x[wave][(k * 4 + (lane >> 4)) * 2 + 1] = b;
+            }
+        }
+        __syncthreads();
+        if (tid < 64 * MW) {
+            const int m = tid >> 1, which = tid & 1;            // row of this block's M extent
+            const int mwi = m >> 5, chl = m & 31;
+            float sum = 0.f;
+#pragma unroll
+            for (int j = 0; j < NW; ++j) sum += stat_x[mwi * NW + j][chl * 2 + which];
+            const int c = blockIdx.y * Cfg::MPAD + m;            // forward: PH == 1, row = output channel
+            if (c < p.Cout) p.stat_part[((size_t)blockIdx.x * p.Cout + c) * 2 + which] = sum;
+        }
+    }
+}
+
+// [B][2C] fp32 block partials -> [256][2C] fp64 chunk partials (bn.hip's ordered finalize takes it from there): chunk j
+// sums blocks [j*B/256, (j+1)*B/256) in order, two half ranges per entry combined through LDS
+__global__ __launch_bounds__(256) void tcn_stat_fold_kernel(const float* __restrict__ part, double* __restrict__ out,
+                                                            int B, int E) {
+    __shared__ double red[256];
+    const int j = blockIdx.x;
+    const int b0 = (int)((long long)B * j / 256), b1 = (int)((long long)B * (j + 1) / 256);
+    for (int e0 = 0; e0 < E; e0 += 128) {
+        const int e = e0 + (threadIdx.x & 127), h = threadIdx.x >> 7;
+        const int mid = b0 + (b1 - b0 + 1) / 2;
+        const int lo = h ? mid : b0, hi = h ? b1 : mid;
+        double s = 0.0;
+        if (e < E)
+            for (int b = lo; b < hi; ++b) s += (double)part[(size_t)b * E + e];
+        red[threadIdx.x] = s;
+        __syncthreads();
+        if (h == 0 && e < E) out[(size_t)j * E + e] = red[threadIdx.x] + red[threadIdx.x + 128];
+        __syncthreads();
     }
 }
 
@@ -293,11 +356,12 @@ __global__ void tcn_pack_kernel(const float* __restrict__ w, float* __restrict__
 }
 
 template <int NT, int KS, int STRIDE, int MW, int NW>
-int launch_tcn(const TcnParams& p, hipStream_t st) {
+int launch_tcn(const TcnParams& p, hipStream_t st, int* nblocks = nullptr) {
     using Cfg = TcnCfg<NT, KS, STRIDE, MW, NW>;
     TcnParams q = p;
     q.nRB = step::ceil_div(p.R, Cfg::RB);
     const long long blocks = (long long)p.N * q.nRB;
+    if (nblocks) *nblocks = (int)blocks;
     if (blocks <= 0 || blocks > 0x7fffffffLL) {
         step::set_error("step_tcn_conv: grid of %lld blocks out of range", blocks);
         return STEP_ERR_ARG;
@@ -329,12 +393,15 @@ extern "C" int step_tcn_pack_weight(const float* w, float* wp, int Co, int Ci, i
     return step::check_launch("step_tcn_pack_weight");
 }
 
-extern "C" int step_tcn_conv(const float* in, const float* in_scale, const float* in_shift,
-                             int in_relu, const float* wp, const float* bias,
-                             const float* out_scale, const float* out_shift, const float* res,
-                             const float* res_scale, const float* res_shift, int out_relu,
-                             float* out, int N, int Ci, int Co, int Tin, int Tout, int Kt,
-                             int stride, int pack_mode, void* stream) {
+namespace {
+// rows (rho) per block of the forward kernels: NT * 4 for every MW x NW shape in use (RB = NW * NT * 2, NW = 2 or 4
+// with NT = 5 -> 20 or 40).  Upper bound of the block count for the statistics workspace: RB >= 16.
+int tcn_conv(const float* in, const float* in_scale, const float* in_shift,
+             int in_relu, const float* wp, const float* bias,
+             const float* out_scale, const float* out_shift, const float* res,
+             const float* res_scale, const float* res_shift, int out_relu,
+             float* out, int N, int Ci, int Co, int Tin, int Tout, int Kt,
+             int stride, int pack_mode, void* stream, float* stat_part, int* nblocks) {
     PackGeom g;
     STEP_REQUIRE(in && wp && out, "step_tcn_conv: null pointer");
     STEP_REQUIRE(N >= 1 && Ci >= 1 && Co >= 1 && Tin >= 1 && Tout >= 1,
@@ -353,6 +420,8 @@ extern "C" int step_tcn_conv(const float* in, const float* in_scale, const float
     p.res = res; p.res_scale = res_scale; p.res_shift = res_shift; p.out_relu = out_relu;
     p.out = out; p.N = N; p.Cin = g.cin_g; p.Cout = g.cout_g; p.Cpad = g.cpad; p.PH = g.ph;
     p.padL = g.padL;
+    p.stat_part = stat_part;
+    STEP_REQUIRE(!stat_part || (pack_mode < 2 && g.ph == 1), "step_tcn_conv_stats: forward pack modes only");
     const bool dgrad = pack_mode >= 2;
     p.Tin = dgrad ? Tout : Tin;                 // rows of the tensor being read
     p.Tout = dgrad ? Tin : Tout;                // rows of the tensor being written
@@ -371,25 +440,71 @@ extern "C" int step_tcn_conv(const float* in, const float* in_scale, const float
     // sequence than NT = 5 (R = 30: 32 instead of 40 rows of MFMA work), ties go to NT = 5 (one A read per 5 MFMAs)
     const bool nt4 = step::ceil_div(p.R, 16) * 16 < step::ceil_div(p.R, 20) * 20;
     switch (key) {
-        case 3814: return nt4 ? launch_tcn<4, 38, 1, 4, 2>(p, st) : launch_tcn<5, 38, 1, 4, 2>(p, st);
-        case 3824: return nt4 ? launch_tcn<4, 38, 2, 4, 2>(p, st) : launch_tcn<5, 38, 2, 4, 2>(p, st);
-        case 514: return launch_tcn<5, 5, 1, 4, 2>(p, st);
-        case 524: return launch_tcn<5, 5, 2, 4, 2>(p, st);
-        case 3811: return launch_tcn<5, 38, 1, 1, 4>(p, st);
-        case 3812: return launch_tcn<5, 38, 1, 2, 2>(p, st);
-        case 3821: return launch_tcn<5, 38, 2, 1, 4>(p, st);
-        case 3822: return launch_tcn<5, 38, 2, 2, 2>(p, st);
-        case 1912: return launch_tcn<5, 19, 1, 2, 2>(p, st);
-        case 1914: return nt4 ? launch_tcn<4, 19, 1, 4, 2>(p, st) : launch_tcn<5, 19, 1, 4, 2>(p, st);
-        case 511: return launch_tcn<5, 5, 1, 1, 4>(p, st);
-        case 512: return launch_tcn<5, 5, 1, 2, 2>(p, st);
-        case 521: return launch_tcn<5, 5, 2, 1, 4>(p, st);
-        case 522: return launch_tcn<5, 5, 2, 2, 2>(p, st);
-        case 312: return launch_tcn<5, 3, 1, 2, 2>(p, st);
-        case 314: return launch_tcn<5, 3, 1, 4, 2>(p, st);
+        case 3814: return nt4 ? launch_tcn<4, 38, 1, 4, 2>(p, st, nblocks) : launch_tcn<5, 38, 1, 4, 2>(p, st, nblocks);
+        case 3824: return nt4 ? launch_tcn<4, 38, 2, 4, 2>(p, st, nblocks) : launch_tcn<5, 38, 2, 4, 2>(p, st, nblocks);
+        case 514: return launch_tcn<5, 5, 1, 4, 2>(p, st, nblocks);
+        case 524: return launch_tcn<5, 5, 2, 4, 2>(p, st, nblocks);
+        case 3811: return launch_tcn<5, 38, 1, 1, 4>(p, st, nblocks);
+        case 3812: return launch_tcn<5, 38, 1, 2, 2>(p, st, nblocks);
+        case 3821: return launch_tcn<5, 38, 2, 1, 4>(p, st, nblocks);
+        case 3822: return launch_tcn<5, 38, 2, 2, 2>(p, st, nblocks);
+        case 1912: return launch_tcn<5, 19, 1, 2, 2>(p, st, nblocks);
+        case 1914: return nt4 ? launch_tcn<4, 19, 1, 4, 2>(p, st, nblocks) : launch_tcn<5, 19, 1, 4, 2>(p, st, nblocks);
+        case 511: return launch_tcn<5, 5, 1, 1, 4>(p, st, nblocks);
+        case 512: return launch_tcn<5, 5, 1, 2, 2>(p, st, nblocks);
+        case 521: return launch_tcn<5, 5, 2, 1, 4>(p, st, nblocks);
+        case 522: return launch_tcn<5, 5, 2, 2, 2>(p, st, nblocks);
+        case 312: return launch_tcn<5, 3, 1, 2, 2>(p, st, nblocks);
+        case 314: return launch_tcn<5, 3, 1, 4, 2>(p, st, nblocks);
         default: break;
     }
     step::set_error("step_tcn_conv: no kernel for Kt=%d stride=%d channels=%d (ks=%d mw=%d)", Kt,
                     stride, g.cout_g, g.ks, mw);
     return STEP_ERR_ARG;
+}
+}  // namespace
+
+extern "C" int step_tcn_conv(const float* in, const float* in_scale, const float* in_shift,
+                             int in_relu, const float* wp, const float* bias,
+                             const float* out_scale, const float* out_shift, const float* res,
+                             const float* res_scale, const float* res_shift, int out_relu,
+                             float* out, int N, int Ci, int Co, int Tin, int Tout, int Kt,
+                             int stride, int pack_mode, void* stream) {
+    return tcn_conv(in, in_scale, in_shift, in_relu, wp, bias, out_scale, out_shift, res, res_scale, res_shift,
+                    out_relu, out, N, Ci, Co, Tin, Tout, Kt, stride, pack_mode, stream, nullptr, nullptr);
+}
+
+// workspace of step_tcn_conv_stats: fp32 block partials (a block covers at least 16 output frames of one sequence),
+// then 256 fp64 chunk partials
+static size_t tcn_stats_part_bytes(int N, int Co, int Tout) {
+    return (size_t)N * step::ceil_div(Tout, 16) * Co * 2 * sizeof(float);
+}
+extern "C" size_t step_tcn_conv_stats_ws_bytes(int N, int Co, int Tout) {
+    if (N < 1 || Co < 1 || Tout < 1) return 0;
+    const size_t a = (tcn_stats_part_bytes(N, Co, Tout) + 255) / 256 * 256 + (size_t)256 * Co * 2 * sizeof(double);
+    const size_t b = step_bn_ws_bytes(Co);
+    return a > b ? a : b;
+}
+
+extern "C" int step_tcn_conv_stats(const float* in, const float* in_scale, const float* in_shift, int in_relu,
+                                   const float* wp, const float* bias, float* out,
+                                   int N, int Ci, int Co, int Tin, int Tout, int Kt, int stride, int pack_mode,
+                                   double* sums, void* ws, size_t ws_bytes, void* stream) {
+    STEP_REQUIRE(sums && ws, "step_tcn_conv_stats: null pointer");
+    STEP_REQUIRE(pack_mode == 0 || pack_mode == 1, "step_tcn_conv_stats: forward pack modes only (got %d)", pack_mode);
+    if (ws_bytes < step_tcn_conv_stats_ws_bytes(N, Co, Tout)) {
+        step::set_error("step_tcn_conv_stats: workspace %zu < %zu bytes", ws_bytes, step_tcn_conv_stats_ws_bytes(N, Co, Tout));
+        return STEP_ERR_WORKSPACE;
+    }
+    float* part = (float*)ws;
+    double* chunks = (double*)((char*)ws + (tcn_stats_part_bytes(N, Co, Tout) + 255) / 256 * 256);
+    int blocks = 0;
+    int rc = tcn_conv(in, in_scale, in_shift, in_relu, wp, bias, nullptr, nullptr, nullptr, nullptr, nullptr, 0, out,
+                      N, Ci, Co, Tin, Tout, Kt, stride, pack_mode, stream, part, &blocks);
+    if (rc != STEP_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(tcn_stat_fold_kernel, dim3(256), dim3(256), 0, st, part, chunks, blocks, 2 * Co);
+    rc = step::check_launch("step_tcn_conv_stats(fold)");
+    if (rc != STEP_OK) return rc;
+    return step::bn_sum_partials(chunks, sums, Co, 256, st);
 }

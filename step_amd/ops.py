@@ -9,6 +9,10 @@ from . import _lib
 
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
+# A/B switch (tools/gpu_ab_step.sh): STEP_SEPARATE_STATS=1 keeps every BatchNorm's statistics as a separate pass over
+# the tensor, as before round 3, instead of taking them in the producing kernel's epilogue
+import os as _os
+_FUSED_STATS = not _os.environ.get("STEP_SEPARATE_STATS")
 
 
 def _ws(nbytes, device):
@@ -385,7 +389,7 @@ class StGcnBlockFn(torch.autograd.Function):
         y = torch.empty((N, Co, T, 16), dtype=torch.float32, device=dev)
         r = torch.empty((N, Co, To, 16), dtype=torch.float32, device=dev) if res_w is not None else None
         rstats = None
-        if training and s.gcn_fwd == "step_gcn_fwd":
+        if training and s.gcn_fwd == "step_gcn_fwd" and _FUSED_STATS:
             # train mode: the graph conv also returns SUM y, SUM y^2 (and the residual conv's) per channel - taken in
             # its epilogue where that kernel form exists, so BN1 / the residual BN never read y / r for statistics
             ysums = torch.empty(2 * Co + 1, dtype=torch.float64, device=dev)
@@ -410,9 +414,22 @@ class StGcnBlockFn(torch.autograd.Function):
         bf = s.bf16_fwd
         wp = tcn_pack(tcn_w, Co, Co, Kt, st, mode, bf16=bf)
         mr = ir = sr = hr = None
-        u = tcn_conv(y, s1, h1, True, wp, tcn_b, None, None, None, None, None, False,
-                     N, Co, Co, T, To, Kt, st, mode, bf16=bf)
-        m2, i2, s2, h2 = bn_prepare(u, 0, s.bn2, training)
+        if training and not bf and _FUSED_STATS:
+            # train mode, fp32 kernel: SUM u, SUM u^2 per channel come out of the conv's epilogue
+            u = torch.empty((N, Co, To, 16), dtype=torch.float32, device=dev)
+            usums = torch.empty(2 * Co + 1, dtype=torch.float64, device=dev)
+            nbt = _lib.query("step_tcn_conv_stats_ws_bytes", N, Co, To)
+            _lib.call("step_tcn_conv_stats", y, s1, h1, 1, wp, tcn_b, u, N, Co, Co, T, To, Kt, st, mode,
+                      usums, _ws(nbt, dev), nbt)
+            synced = _sync_world() > 1
+            if synced:
+                usums[2 * Co] = float(N * To * 16)
+                _sync_sums(usums)
+            m2, i2, s2, h2 = bn_finalize_sums(usums, N * To * 16, s.bn2, synced)
+        else:
+            u = tcn_conv(y, s1, h1, True, wp, tcn_b, None, None, None, None, None, False,
+                         N, Co, Co, T, To, Kt, st, mode, bf16=bf)
+            m2, i2, s2, h2 = bn_prepare(u, 0, s.bn2, training)
         res_t = None
         if s.residual == "conv":
             mr, ir, sr, hr = rstats if rstats is not None else bn_prepare(r, 0, s.bnr, training)

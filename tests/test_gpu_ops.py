@@ -614,3 +614,38 @@ def test_gcn_fwd_stats_epilogue(Ci, Co, T, N, stride, res, tr):
         got = sm[:2 * Co].view(Co, 2)
         assert float((got[:, 0] - ref1).abs().max()) <= 2e-6 * float(td.abs().sum(dim=(0, 2, 3)).max()), name
         assert float(((got[:, 1] - ref2) / ref2).abs().max()) <= 2e-6, name
+
+
+@pytest.mark.parametrize("C,stride,T,N,tr", [(32, 1, 33, 3, False), (64, 2, 41, 2, False), (64, 1, 240, 5, False),
+                                             (64, 2, 240, 3, False), (32, 1, 24, 2, True), (128, 1, 30, 2, False),
+                                             (3, 1, 20, 2, True)])
+def test_tcn_conv_stats_epilogue(C, stride, T, N, tr):
+    """step_tcn_conv_stats: u bit-equal to step_tcn_conv's, [SUM u, SUM u^2] per channel equal to float64 sums of u
+    (ragged T: blocks whose last waves lie past the sequence end; stride 2; ConvTranspose packing; 128 channels on
+    two output groups; the 64 -> 3 decoder layer), and bit-identical over two calls"""
+    from step_amd import _lib, ops
+    d = dev()
+    g = torch.Generator().manual_seed(C + T)
+    Ci = 64 if C == 3 else C
+    Co = C
+    To = (T - 1) // stride + 1
+    y = torch.randn(N, Ci, T, 16, generator=g).to(d)
+    w = (torch.randn(Ci, Co, 75, 1, generator=g) if tr else torch.randn(Co, Ci, 75, 1, generator=g)).to(d) * 0.05
+    b = torch.randn(Co, generator=g).to(d)
+    sc, sh = (torch.rand(Ci, generator=g) + 0.5).to(d), torch.randn(Ci, generator=g).to(d) * 0.3
+    mode = 1 if tr else 0
+    wp = ops.tcn_pack(w, Co, Ci, 75, stride, mode)
+    ref = ops.tcn_conv(y, sc, sh, True, wp, b, None, None, None, None, None, False, N, Ci, Co, T, To, 75, stride, mode)
+    nb = _lib.query("step_tcn_conv_stats_ws_bytes", N, Co, To)
+    res = []
+    for _ in range(2):
+        u = torch.full((N, Co, To, 16), float("nan"), device=d)
+        sums = torch.zeros(2 * Co + 1, dtype=torch.float64, device=d)
+        ws = torch.empty(nb, dtype=torch.uint8, device=d)
+        _lib.call("step_tcn_conv_stats", y, sc, sh, 1, wp, b, u, N, Ci, Co, T, To, 75, stride, mode, sums, ws, nb)
+        res.append((u, sums))
+    assert torch.equal(res[0][0], ref) and torch.equal(res[0][1], res[1][1])
+    ud = ref.double()
+    got = res[0][1][:2 * Co].view(Co, 2)
+    assert float((got[:, 0] - ud.sum(dim=(0, 2, 3))).abs().max()) <= 2e-6 * float(ud.abs().sum(dim=(0, 2, 3)).max())
+    assert float(((got[:, 1] - (ud * ud).sum(dim=(0, 2, 3))) / (ud * ud).sum(dim=(0, 2, 3))).abs().max()) <= 2e-6
