@@ -15,6 +15,14 @@
 // activation strip is a ring of frames (see WsCfg): per chunk only the S*TT new frames are fetched, the whole
 // strip once per sequence.  Slices of the batch are combined by the ordered reduce of tcn_wgrad.hip
 // (bit-reproducible).
+// Round 3, what the ablations said (C = 64, stride 2, N = 4096; 36.7 ms = 0.837 of the fp32 MFMA peak before): feeding
+// the MFMAs pre-activated fragments (no BN + ReLU VALU in the MFMA waves) changes nothing; the bias sums change nothing;
+// no slab store, no sequence-start barrier: nothing; no per-chunk barrier: -1.5 %; no DMA at all: -6 %; and 256 extra
+// v_fma per chunk in the STAGING waves: +23 %.  An instruction a staging wave issues costs the MFMA wave on its SIMD
+// time, and the staging waves spent ~30 VALU instructions per 1-KiB DMA piece on addresses (a division among them).
+// With per-lane constant offsets and uniform bases (one v_lshl_add_u64 per piece): 35.1 ms = 0.875 at stride 2,
+// 68.5 ms = 0.897 at stride 1 (T = 240), 17.8 ms = 0.86 at 32 channels; with DMA and barriers off the MFMA loop alone
+// runs at 0.887 of the peak in this two-launch form (75 of 76 tap slots useful, 252 of 256 CUs busy).
 #include "common.h"
 #include <type_traits>
 #include <cstdlib>
@@ -98,6 +106,14 @@ __device__ __forceinline__ int xcd_contiguous_id(int b, int first, int count) {
     return before + (b - f) / 8;
 }
 
+// A uniform address the optimiser may not fold into the lanes' offsets: kept as an SGPR pair, so that `base + offset`
+// stays (uniform base) + (32-bit lane offset) and the DMA takes its saddr + voffset form with no VALU instruction.
+__device__ __forceinline__ const char* sgpr_base(const void* q) {
+    unsigned long long v = reinterpret_cast<unsigned long long>(q);
+    asm volatile("" : "+s"(v));
+    return reinterpret_cast<const char*>(v);
+}
+
 template <int MW, int NJ, int STRIDE, int TT, int BF>
 __device__ __forceinline__ void ws_body(const WsParams& p, const int lb, char* smem) {
     using C = WsCfg<MW, NJ, STRIDE, TT>;
@@ -132,10 +148,37 @@ __device__ __forceinline__ void ws_body(const WsParams& p, const int lb, char* s
         constexpr int DCH = 32 * MW * CPR;                        // chunks of the image
         constexpr int NPIECE = C::D_BYTES / 1024;
         constexpr int DPW = (NPIECE + C::NPROD - 1) / C::NPROD;   // DMA instructions per wave
+        // Address work of these waves is kept off the vector ALU: an instruction a staging wave issues costs the MFMA
+        // wave on its SIMD time (measured: 256 extra v_fma per chunk here = +23 % kernel time), and the first version
+        // spent ~30 VALU instructions per DMA piece (a division by CPR among them).  The lane's byte offset inside an
+        // item is a per-lane CONSTANT (doff), the item's (n, t0) part is uniform and stays in SGPRs: saddr + voffset.
+        unsigned doff[DPW];
+#pragma unroll
+        for (int k = 0; k < DPW; ++k) {
+            const int c = (k * C::NPROD + pwave) * 64 + lane;
+            const int co = c / CPR, slot = c - co * CPR;
+            const int w = slot < CPR - 1 ? slot : 0;
+            // rows past Co (never with the channel counts ws_geom admits) and the tail pad of the image re-read the
+            // item's first chunk: those bytes are never used
+            doff[k] = (c < DCH && co0 + co < p.Co) ? (unsigned)((((co0 + co) * p.Tout + (w >> 2)) * 16 + (w & 3) * 4) * 4) : 0u;
+        }
         auto dma_dout = [&](int item, char* img) {
             const int n = n0 + item / nchunks;
             const int t0 = (item % nchunks) * TT;
             const float* dbase = p.dout + (size_t)n * p.Co * p.Tout * 16;
+            if (t0 + TT <= p.Tout) {
+                const char* ibase = sgpr_base(dbase + (size_t)t0 * 16);
+#pragma unroll
+                for (int k = 0; k < DPW; ++k) {
+                    const int piece = k * C::NPROD + pwave;
+                    if (piece < NPIECE)
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ibase + doff[k]),
+                                                         (__attribute__((address_space(3))) void*)(img + piece * 1024),
+                                                         16, 0, 0);
+                }
+                return;
+            }
+            // the sequence's last chunk when TT does not divide Tout: frames past the end copy from the zero line
 #pragma unroll
             for (int k = 0; k < DPW; ++k) {
                 const int piece = k * C::NPROD + pwave;           // 1 KiB piece of the image
@@ -176,9 +219,20 @@ __device__ __forceinline__ void ws_body(const WsParams& p, const int lb, char* s
         // quarter that the swizzle maps there.
         char* aring = smem + C::A_BASE;
         const int pch = lane >> 2;                                  // channel within the piece
+        // per-lane constant byte offsets of the two half-frames (channels 0..15 | 16..31 of the block's 32; ws_geom
+        // admits only channel counts that are multiples of 32, so every channel exists); the frame and sample part of
+        // the address is uniform
+        unsigned aoff[2];
+#pragma unroll
+        for (int hp = 0; hp < 2; ++hp) {
+            const int ch = 16 * hp + pch;
+            const int q = ((lane & 3) - (ch >> 2)) & 3;
+            aoff[hp] = (unsigned)(((ci0 + ch) * p.Tin * 16 + q * 4) * 4);
+        }
         auto dma_frames = [&](auto count_tag, int n, int frame_first, int slot_first) {
             constexpr int COUNT = decltype(count_tag)::value;
             constexpr int PER = (2 * COUNT + C::NPROD - 1) / C::NPROD;
+            const float* nbase = p.in + (size_t)n * p.Ci * p.Tin * 16;
 #pragma unroll
             for (int k0 = 0; k0 < PER; ++k0) {
                 const int k = k0 * C::NPROD + pwave;
@@ -186,13 +240,14 @@ __device__ __forceinline__ void ws_body(const WsParams& p, const int lb, char* s
                     const int fi = k >> 1, hp = k & 1;
                     int slot = slot_first + fi;
                     slot = slot >= C::RING ? slot - C::RING : slot;
-                    const int frame = frame_first + fi;
-                    const int ch = 16 * hp + pch;
-                    const int q = ((lane & 3) - (ch >> 2)) & 3;
-                    const float* src = ((unsigned)frame < (unsigned)p.Tin && ci0 + ch < p.Ci)
-                                           ? p.in + (((size_t)n * p.Ci + ci0 + ch) * p.Tin + frame) * 16 + q * 4
-                                           : p.zeros;
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                    // Frames outside the sequence: the MFMA waves multiply what lands by scale = shift = 0, so it only
+                    // has to be finite - the nearest frame of the sequence is fetched instead (scalar min / max, no
+                    // branch, no per-lane select; a non-finite activation anywhere makes dw non-finite either way).
+                    int frame = frame_first + fi;
+                    frame = frame < 0 ? 0 : frame;
+                    frame = frame < p.Tin ? frame : p.Tin - 1;
+                    const char* src = sgpr_base(nbase + (size_t)frame * 16);
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + aoff[hp]),
                                                      (__attribute__((address_space(3))) void*)(aring + slot * C::FRAME_BYTES + hp * 1024),
                                                      16, 0, 0);
                 }

@@ -6,6 +6,8 @@ tail -1 gpurun_out/pytest_wgrad.log
 for s in 1 2; do
   timeout -k 10 100 python -u tools/kbench.py wgrad --n 4096 --c 64 --stride $s --t 240 --reps 3
   timeout -k 10 100 python -u tools/kbench.py wgrad --n 4096 --c 64 --stride $s --t 240 --reps 3 --bf16
+  timeout -k 10 100 python -u tools/kbench.py wgrad --n 4096 --c 64 --stride $s --t 240 --reps 3 --split
 done
 timeout -k 10 100 python -u tools/kbench.py wgrad --n 4096 --c 32 --stride 1 --t 240 --reps 3
 timeout -k 10 100 python -u tools/kbench.py wgrad --n 4096 --c 32 --stride 1 --t 240 --reps 3 --bf16
+timeout -k 10 100 python -u tools/kbench.py wgrad --n 4096 --c 32 --stride 1 --t 240 --reps 3 --split
