@@ -122,6 +122,8 @@ def time_hbm_kernels(n, t, device, reps=3):
                                                     (64, 64, (t - 1) // 2 + 1, 1, False)]):
         to = (tt - 1) // st + 1
         x = torch.randn(n, ci, tt, 16, generator=g).to(device)
+        if bi > 0:
+            x.relu_()        # blocks 1-2 read the previous block's output, a ReLU result (classifier.py:166,191): half zeros
         w = (torch.randn(3 * co, ci, generator=g) * 0.1).to(device)
         b = torch.zeros(3 * co, device=device)
         y = torch.empty(n, co, tt, 16, device=device)
@@ -422,6 +424,19 @@ def main():
         if args.mfma == "f32":          # MFMA utilisation of the wide layers (kernel-level bench points, N = batch / 2)
             torch.cuda.empty_cache()
             kernels = kernels + time_kernels(max(1, args.batch // 2), args.frames, device, blocks=WIDE_BLOCKS, tag="wide")
+        if bf16_run is not None:
+            # roofline of the bf16-operand step's dominant kernel, against the nominal dense bf16 MFMA peak and against
+            # what register-only bf16 MFMAs sustain on this box at the clock they pull (tools/mfma_peak.hip)
+            torch.cuda.empty_cache()
+            kb = time_kernels(args.batch, args.frames, device, bf16=True)
+            domb = max(kb, key=lambda k: k["ms"])
+            bf16_run["kernels"] = kb
+            bf16_run["roofline"] = {"bound": "mfma", "kernel": domb["kernel"], "achieved": domb["tflops"],
+                                    "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": domb["frac"],
+                                    "sustained_on_this_box": [1580.0, 1840.0],
+                                    "frac_of_sustained": [round(domb["tflops"] / 1840.0, 4), round(domb["tflops"] / 1580.0, 4)],
+                                    "traffic": None}
+            torch.cuda.empty_cache()
         traffic, traffic_src = (pmc_traffic(dom["kernel"], args.batch, args.frames) if args.mfma == "f32"
                                 else (None, None))
         roof = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"],

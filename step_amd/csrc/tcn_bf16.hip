@@ -17,6 +17,7 @@
 // on 2*S*i + jj, so a wave keeps a sliding window of fragments and reads each once.
 #include "common.h"
 #include "tcn_pack.h"
+#include <type_traits>
 
 namespace {
 
@@ -27,6 +28,14 @@ using step::pack_value;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ s16x2 pk_bf16(float a, float b) {
+    return __builtin_bit_cast(s16x2, __builtin_convertvector(f32x2{a, b}, bf16x2));
+}
 typedef __attribute__((address_space(3))) bf16x4* lds_bf16x4_ptr;
 
 struct TbParams {
@@ -61,8 +70,6 @@ struct TbCfg {
     static constexpr int STAGE_BYTES = 4 * 32 * 32 * 4;       // output stages: one 32 x 32 tile per MFMA wave
     static constexpr int LDS_BYTES = 2 * STRIP_BYTES + STAGE_BYTES;   // double-buffered strips + stages
     static constexpr int GCH = SPLIT ? 8 : 16;                // input channels of one group (one MFMA's K = 16)
-    static constexpr int ITEMS = GCH * ROWS * 4;              // float4 items of one group
-    static constexpr int SF4 = (ITEMS + PTHR - 1) / PTHR;
     static constexpr int NBTOT = STRIDE * 2 * (NT - 1) + KT2; // B fragments of one group
     static constexpr int NB0 = STRIDE * 2 * (NT - 1) + 1;     // ... needed by tap 0
     static_assert(CHS >= ROWS * 32, "strip row");
@@ -76,6 +83,10 @@ struct TbCfg {
 // bring item i+1 (next group, or the next tile's first group) into the other: HBM -> registers
 // -> BN + ReLU -> bf16 -> LDS.  One barrier per item; the two roles never touch the same buffer
 // between barriers, and the staging loads never sit in front of the MFMA waves' operand loads.
+// Round 3 ablations (64 -> 64, stride 1, T = 120, N = 4096, 4.2 ms): every tap reading the same A fragment (all L1
+// hits): -2 %; no staging at all: -10 % (3.7 ms = 1.3 PFLOP/s, against the 1.58-1.84 PFLOP/s this box sustains on
+// register-only bf16 MFMAs at the 1.7-1.87 GHz they pull the clock to).  The staging rewrite below (6-10 VALU
+// instructions per float4 instead of ~35) is worth 5 % in the split mode and nothing measurable in the bf16 mode.
 //
 // SPLIT (fp32 operands at bf16-MFMA speed): a group is 8 channels, each as TWO strip rows - hi = bf16(v) and
 // lo = bf16(v - hi), k = 2*channel + part - and a tap takes two MFMAs: A = [w_hi, w_hi] pairs against (hi, lo) gives
@@ -99,57 +110,89 @@ __global__ __launch_bounds__(64 * (MW * NW + NPROD)) void tcn_bf16_kernel(TbPara
         // the MFMA wave on this SIMD always has an instruction ready and would win every
         // arbitration; the staging wave issues rarely (it mostly waits on memory) but must not queue
         __builtin_amdgcn_s_setprio(3);
-        float4 sreg[Cfg::SF4];
+        // Thread -> (channel row c of the group, position li among the row's TPCH threads); the row's float4 items
+        // li, li + TPCH, ... are a linear walk of the tensor's channel row AND of the strip row, so both addresses are
+        // one per-item base plus compile-time offsets, scale / shift are two values per thread, and only tiles that
+        // touch an end of the sequence test positions.  (An instruction a staging wave issues costs the MFMA wave on
+        // its SIMD time - tcn_wgrad_sw.hip; the first version spent ~35 VALU instructions per float4 here.)
+        constexpr int TPCH = Cfg::PTHR / Cfg::GCH;
+        constexpr int RI = Cfg::ROWS * 4;                        // float4 items of one channel row
+        constexpr int NK = (RI + TPCH - 1) / TPCH;
+        const int c = ptid / TPCH, li = ptid % TPCH;
+        f32x4 sreg[NK];
+        auto tile_t0 = [&](int tile) { return STRIDE * (tile % p.nRB) * Cfg::RB - p.padL; };   // input frame of strip row 0
         // HBM -> registers (raw); the loads stay in flight across the barrier
         auto load_regs = [&](int tile, int g) {
             const int n = tile / p.nRB;
-            const int tin0 = STRIDE * (tile % p.nRB) * Cfg::RB - p.padL;   // input frame of strip row 0
+            const int tin0 = tile_t0(tile);
+            const f32x4* row = reinterpret_cast<const f32x4*>(p.in + ((size_t)n * p.Cin + Cfg::GCH * g + c) * p.Tin * 16);
+            const int e0 = tin0 * 4 + li;
+            if (tin0 >= 0 && tin0 + Cfg::ROWS <= p.Tin) {        // (uniform) every frame of the strip exists
 #pragma unroll
-            for (int k = 0; k < Cfg::SF4; ++k) {
-                const int f = ptid + k * Cfg::PTHR;
-                const int c = f / (Cfg::ROWS * 4);
-                const int rem = f - c * (Cfg::ROWS * 4);
-                const int tin = tin0 + (rem >> 2);
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (f < Cfg::ITEMS && tin >= 0 && tin < p.Tin)
-                    v = *reinterpret_cast<const float4*>(
-                        p.in + (((size_t)n * p.Cin + Cfg::GCH * g + c) * p.Tin + tin) * 16 + (rem & 3) * 4);
-                sreg[k] = v;
+                for (int k = 0; k < NK; ++k) {
+                    if ((k + 1) * TPCH <= RI || li + k * TPCH < RI) sreg[k] = row[e0 + k * TPCH];
+                }
+            } else {
+                const unsigned lim = (unsigned)p.Tin * 4u;
+#pragma unroll
+                for (int k = 0; k < NK; ++k) {
+                    const int e = e0 + k * TPCH;
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                    if ((unsigned)e < lim && ((k + 1) * TPCH <= RI || li + k * TPCH < RI)) v = row[e];
+                    sreg[k] = v;
+                }
             }
         };
         // registers -> tcn[0] scale/shift, tcn[1] ReLU -> bf16 -> LDS; padding frames stay exactly
         // zero (the reference pads after the activation)
-        auto store_regs = [&](int tile, int g, char* buf) {
-            const int tin0 = STRIDE * (tile % p.nRB) * Cfg::RB - p.padL;
+        auto store_body = [&](auto act_tag, auto relu_tag, auto edge_tag, int tile, int g, char* buf) {
+            constexpr bool ACT = decltype(act_tag)::value, RELU = decltype(relu_tag)::value, EDGE = decltype(edge_tag)::value;
+            float sc = 1.f, sh = 0.f;
+            if constexpr (ACT) { sc = p.in_scale[Cfg::GCH * g + c]; sh = p.in_shift[Cfg::GCH * g + c]; }
+            const int e0 = tile_t0(tile) * 4 + li;
+            const unsigned lim = (unsigned)p.Tin * 4u;
+            char* dst = buf + (SPLIT ? 2 * c : c) * Cfg::CHS + li * 8;
 #pragma unroll
-            for (int k = 0; k < Cfg::SF4; ++k) {
-                const int f = ptid + k * Cfg::PTHR;
-                if (f < Cfg::ITEMS) {
-                    const int c = f / (Cfg::ROWS * 4);
-                    const int rem = f - c * (Cfg::ROWS * 4);
-                    const int lr = rem >> 2;
-                    const int tin = tin0 + lr;
-                    f32x4 v = {sreg[k].x, sreg[k].y, sreg[k].z, sreg[k].w};
-                    if (tin >= 0 && tin < p.Tin) {
-                        if (p.in_scale) {
-                            const float sc = p.in_scale[Cfg::GCH * g + c], sh = p.in_shift[Cfg::GCH * g + c];
-                            v = v * sc + sh;
-                        }
-                        if (p.in_relu) {
-                            v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f);
-                            v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
-                        }
+            for (int k = 0; k < NK; ++k) {
+                if ((k + 1) * TPCH > RI && li + k * TPCH >= RI) continue;      // (only the row's last, partial step tests)
+                f32x4 v = sreg[k];
+                if constexpr (ACT) {
+                    float s1 = sc, s0 = sh;
+                    if constexpr (EDGE) {                        // outside the sequence: 0 * 0 + 0 (the load gave zeros)
+                        const bool in = (unsigned)(e0 + k * TPCH) < lim;
+                        s1 = in ? sc : 0.f; s0 = in ? sh : 0.f;
                     }
-                    if constexpr (SPLIT) {
-                        const bf16x4 hi = __builtin_convertvector(v, bf16x4);
-                        const bf16x4 lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x4), bf16x4);
-                        *reinterpret_cast<bf16x4*>(buf + (2 * c) * Cfg::CHS + lr * 32 + (rem & 3) * 8) = hi;
-                        *reinterpret_cast<bf16x4*>(buf + (2 * c + 1) * Cfg::CHS + lr * 32 + (rem & 3) * 8) = lo;
-                    } else {
-                        *reinterpret_cast<bf16x4*>(buf + c * Cfg::CHS + lr * 32 + (rem & 3) * 8) =
-                            __builtin_convertvector(v, bf16x4);
-                    }
+                    v = v * s1 + s0;
                 }
+                if constexpr (SPLIT) {
+                    if constexpr (RELU) {
+                        v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+                    }
+                    const bf16x4 hi = __builtin_convertvector(v, bf16x4);
+                    const bf16x4 lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x4), bf16x4);
+                    *reinterpret_cast<bf16x4*>(dst + k * TPCH * 8) = hi;
+                    *reinterpret_cast<bf16x4*>(dst + Cfg::CHS + k * TPCH * 8) = lo;
+                } else {
+                    // rounding is monotonic and keeps the sign, so ReLU commutes with it: on the packed bf16 pair it is
+                    // a signed 16-bit max with 0 (one instruction per two values)
+                    s16x2 h0 = pk_bf16(v[0], v[1]), h1 = pk_bf16(v[2], v[3]);     // (one v_cvt_pk_bf16_f32 each)
+                    if constexpr (RELU) {
+                        h0 = __builtin_elementwise_max(h0, s16x2{0, 0});
+                        h1 = __builtin_elementwise_max(h1, s16x2{0, 0});
+                    }
+                    *reinterpret_cast<s16x4*>(dst + k * TPCH * 8) = __builtin_shufflevector(h0, h1, 0, 1, 2, 3);
+                }
+            }
+        };
+        auto store_regs = [&](int tile, int g, char* buf) {
+            using T = std::true_type; using F = std::false_type;
+            const int tin0 = tile_t0(tile);
+            const bool edge = !(tin0 >= 0 && tin0 + Cfg::ROWS <= p.Tin);
+            if (p.in_scale) {
+                if (p.in_relu) { if (edge) store_body(T{}, T{}, T{}, tile, g, buf); else store_body(T{}, T{}, F{}, tile, g, buf); }
+                else           { if (edge) store_body(T{}, F{}, T{}, tile, g, buf); else store_body(T{}, F{}, F{}, tile, g, buf); }
+            } else {
+                if (p.in_relu) store_body(F{}, T{}, F{}, tile, g, buf); else store_body(F{}, F{}, F{}, tile, g, buf);
             }
         };
         // item sequence of this block: (tile, g) with g fastest
