@@ -23,6 +23,9 @@
 // With per-lane constant offsets and uniform bases (one v_lshl_add_u64 per piece): 35.1 ms = 0.875 at stride 2,
 // 68.5 ms = 0.897 at stride 1 (T = 240), 17.8 ms = 0.86 at 32 channels; with DMA and barriers off the MFMA loop alone
 // runs at 0.887 of the peak in this two-launch form (75 of 76 tap slots useful, 252 of 256 CUs busy).
+// Also tried: no staging waves, 8 MFMA waves (tap group x M tile, two per SIMD, 80 accumulator registers each) that
+// issue the DMA themselves (through inline asm - the compiler waits vmcnt(0) before the first LDS read after an
+// LDS-DMA it knows of): correct, but 37.1 ms against 35.0 - every B fragment is then read and activated by two waves.
 #include "common.h"
 #include <type_traits>
 #include <cstdlib>
