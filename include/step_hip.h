@@ -300,6 +300,12 @@ int step_tcn_wgrad_bf16(const float* dout, const float* in, const float* in_scal
                         const float* in_shift, int in_relu, float* dw, float* db,
                         int N, int Ci, int Co, int Tin, int Tout, int Kt, int stride,
                         void* ws, size_t ws_bytes, void* stream);
+/* the same with `transposed` as in step_tcn_wgrad: the ConvTranspose2d layout (Ci,Co,Kt) of the st_gctn blocks'
+ * tcn[2] (generator_cvae/net/CVAE_stgcn.py:359-365; stride 1 only), so that the bf16 mode covers the CVAE     */
+int step_tcn_wgrad_bf16_t(const float* dout, const float* in, const float* in_scale,
+                          const float* in_shift, int in_relu, float* dw, float* db,
+                          int N, int Ci, int Co, int Tin, int Tout, int Kt, int stride, int transposed,
+                          void* ws, size_t ws_bytes, void* stream);
 
 /* The split-operand twins of step_tcn_packed_bytes_bf16 / step_tcn_pack_weight_bf16 / step_tcn_conv_bf16: fp32
  * operands enter the bf16 matrix cores as hi = bf16(v) and lo = bf16(v - hi) (16 mantissa bits); a group is 8 input

@@ -149,10 +149,10 @@ class _TemporalConvBf16Operands(torch.autograd.Function):
     beside north_star's 1e-2 against the plain fp32 path."""
 
     @staticmethod
-    def forward(ctx, a, weight, bias, stride):
+    def forward(ctx, a, weight, bias, stride, transposed=False):
         ctx.save_for_backward(a, weight)
-        ctx.stride = stride
-        return temporal_conv(_rb(a), _rb(weight), bias, stride)
+        ctx.stride, ctx.transposed = stride, transposed
+        return temporal_conv(_rb(a), _rb(weight), bias, stride, transposed)
 
     @staticmethod
     def backward(ctx, dout):
@@ -160,9 +160,9 @@ class _TemporalConvBf16Operands(torch.autograd.Function):
         ar = _rb(a).detach().requires_grad_(True)
         wr = _rb(weight).detach().requires_grad_(True)
         with torch.enable_grad():
-            out = temporal_conv(ar, wr, None, ctx.stride)
+            out = temporal_conv(ar, wr, None, ctx.stride, ctx.transposed)
         da, dw = torch.autograd.grad(out, (ar, wr), _rb(dout))
-        return da, dw, dout.sum(dim=(0, 2, 3)), None
+        return da, dw, dout.sum(dim=(0, 2, 3)), None, None
 
 
 def st_gcn_block(x, A_eff, P, prefix, stride, residual, training,
@@ -185,8 +185,12 @@ def st_gcn_block(x, A_eff, P, prefix, stride, residual, training,
     y = conv_temporal_graphical(x, A_eff, P[prefix + "." + gname + ".conv.weight"],
                                 P[prefix + "." + gname + ".conv.bias"], transposed)
     a = torch.relu(bn2d(y, P, prefix + ".tcn.0", training, update_running))
-    if tcn_bf16 and not transposed:
-        u = _TemporalConvBf16Operands.apply(a, P[prefix + ".tcn.2.weight"], P[prefix + ".tcn.2.bias"], stride)
+    # tcn_bf16: True, or a predicate on the conv's channel count (the kernels cover square 32- / 64-channel convs;
+    # the CVAE decoder's last block, 3 -> 3, stays on fp32 operands)
+    tw = P[prefix + ".tcn.2.weight"]
+    if tcn_bf16(tw.shape[0]) if callable(tcn_bf16) else tcn_bf16:
+        u = _TemporalConvBf16Operands.apply(a, P[prefix + ".tcn.2.weight"], P[prefix + ".tcn.2.bias"], stride,
+                                            transposed)
     else:
         u = temporal_conv(a, P[prefix + ".tcn.2.weight"], P[prefix + ".tcn.2.bias"],
                           stride, transposed)
@@ -247,12 +251,12 @@ def classifier_extract_feature(P, x, variant="real_only"):
 
 
 # ------------------------------------------------------------------------ CVAE
-def encoder_forward(P, x, l, training=False, prefix="encoder", update_running=True):
+def encoder_forward(P, x, l, training=False, prefix="encoder", update_running=True, tcn_bf16=False):
     """Encoder.forward CVAE_stgcn.py:108-136.  x (N,3,T,V,1), l (N,cls,T,V,1)."""
     h = torch.cat((x, l), dim=1)[..., 0]
     h = data_bn(h, P, prefix + ".data_bn", training, update_running)
     h = _stack(h, P, "cvae_encoder", prefix + ".encoder", prefix + ".edge_importance",
-               P[prefix + ".A"].to(x.dtype), training, False, update_running)
+               P[prefix + ".A"].to(x.dtype), training, False, update_running, tcn_bf16=tcn_bf16)
     pooled = h.mean(dim=(2, 3))
     wm, wl = P[prefix + ".z_mean.weight"], P[prefix + ".z_lsig.weight"]
     mean = pooled @ wm.reshape(wm.shape[0], -1).t() + P[prefix + ".z_mean.bias"]
@@ -260,23 +264,23 @@ def encoder_forward(P, x, l, training=False, prefix="encoder", update_running=Tr
     return mean, lsig
 
 
-def decoder_forward(P, z, l, T, V, training=False, prefix="decoder", update_running=True):
+def decoder_forward(P, z, l, T, V, training=False, prefix="decoder", update_running=True, tcn_bf16=False):
     """Decoder.forward CVAE_stgcn.py:198-232.  Returns (N,C,T,V,1)."""
     zl = torch.cat((z, l), dim=1)
     w = P[prefix + ".fcn.weight"]                  # ConvTranspose2d weight (in, out, 1, 1)
     h = zl @ w.reshape(w.shape[0], w.shape[1]) + P[prefix + ".fcn.bias"]
     h = h[:, :, None, None].expand(-1, -1, T, V)
     h = _stack(h, P, "cvae_decoder", prefix + ".decoder", prefix + ".edge_importance",
-               P[prefix + ".A"].to(z.dtype), training, True, update_running)
+               P[prefix + ".A"].to(z.dtype), training, True, update_running, tcn_bf16=tcn_bf16)
     h = data_bn(h, P, prefix + ".data_bn", training, update_running)
     return h.unsqueeze(-1)
 
 
-def cvae_forward(P, x, lenc, ldec, eps, T, V, training=False, update_running=True):
+def cvae_forward(P, x, lenc, ldec, eps, T, V, training=False, update_running=True, tcn_bf16=False):
     """CVAE.forward CVAE_stgcn.py:25-37 with the reparameterisation noise given."""
-    mean, lsig = encoder_forward(P, x, lenc, training, "encoder", update_running)
+    mean, lsig = encoder_forward(P, x, lenc, training, "encoder", update_running, tcn_bf16=tcn_bf16)
     z = eps * torch.exp(0.5 * lsig) + mean
-    recon = decoder_forward(P, z, ldec, T, V, training, "decoder", update_running)
+    recon = decoder_forward(P, z, ldec, T, V, training, "decoder", update_running, tcn_bf16=tcn_bf16)
     return recon, mean, lsig, z
 
 

@@ -60,6 +60,7 @@ SIGNATURES = {
     "step_tcn_wgrad": (I, [P, P, P, P, I, P, P, I, I, I, I, I, I, I, I, P, Z, P]),
     "step_tcn_wgrad_bf16_ws_bytes": (Z, [I, I, I, I, I, I, I]),
     "step_tcn_wgrad_bf16": (I, [P, P, P, P, I, P, P, I, I, I, I, I, I, I, P, Z, P]),
+    "step_tcn_wgrad_bf16_t": (I, [P, P, P, P, I, P, P, I, I, I, I, I, I, I, I, P, Z, P]),
     "step_tcn_wgrad_split": (I, [P, P, P, P, I, P, P, I, I, I, I, I, I, I, I, P, Z, P]),
     "step_vae_loss_ws_bytes": (Z, [I]),
     "step_vae_loss": (I, [P, P, P, P, F, P, P, P, P, I, I, I, I, I, P, Z, P]),

@@ -13,10 +13,11 @@ extern "C" size_t step_tcn_wgrad_bf16_ws_bytes(int N, int Ci, int Co, int Tin, i
     return step::wgrad_sw_ws_bytes(N, Ci, Co, Kt, stride);
 }
 
-extern "C" int step_tcn_wgrad_bf16(const float* dout, const float* in, const float* in_scale,
+static int wgrad_bf16(const float* dout, const float* in, const float* in_scale,
                                    const float* in_shift, int in_relu, float* dw, float* db, int N, int Ci,
-                                   int Co, int Tin, int Tout, int Kt, int stride, void* ws, size_t ws_bytes,
-                                   void* stream) {
+                                   int Co, int Tin, int Tout, int Kt, int stride, int transposed, void* ws,
+                                   size_t ws_bytes, void* stream) {
+    STEP_REQUIRE(!transposed || stride == 1, "step_tcn_wgrad_bf16_t: transposed needs stride 1");
     STEP_REQUIRE(dout && in && dw && ws, "step_tcn_wgrad_bf16: null pointer");
     STEP_REQUIRE(N > 0 && Tin > 0 && (stride == 1 || stride == 2) && Tout == (Tin - 1) / stride + 1,
                  "step_tcn_wgrad_bf16: bad shape Tin=%d Tout=%d stride=%d", Tin, Tout, stride);
@@ -27,8 +28,25 @@ extern "C" int step_tcn_wgrad_bf16(const float* dout, const float* in, const flo
         step::set_error("step_tcn_wgrad_bf16: workspace %zu < %zu bytes", ws_bytes, need);
         return STEP_ERR_WORKSPACE;
     }
-    return step::wgrad_sw(dout, in, in_scale, in_shift, in_relu, dw, db, N, Ci, Co, Tin, Tout, Kt, stride, 0,
-                          ws, ws_bytes, (hipStream_t)stream, 1);
+    return step::wgrad_sw(dout, in, in_scale, in_shift, in_relu, dw, db, N, Ci, Co, Tin, Tout, Kt, stride,
+                          transposed, ws, ws_bytes, (hipStream_t)stream, 1);
+}
+
+extern "C" int step_tcn_wgrad_bf16(const float* dout, const float* in, const float* in_scale,
+                                   const float* in_shift, int in_relu, float* dw, float* db, int N, int Ci,
+                                   int Co, int Tin, int Tout, int Kt, int stride, void* ws, size_t ws_bytes,
+                                   void* stream) {
+    return wgrad_bf16(dout, in, in_scale, in_shift, in_relu, dw, db, N, Ci, Co, Tin, Tout, Kt, stride, 0, ws,
+                      ws_bytes, stream);
+}
+
+// the same with the ConvTranspose2d weight layout (Ci, Co, Kt), taps reversed (st_gctn blocks, CVAE_stgcn.py:359-365)
+extern "C" int step_tcn_wgrad_bf16_t(const float* dout, const float* in, const float* in_scale,
+                                     const float* in_shift, int in_relu, float* dw, float* db, int N, int Ci,
+                                     int Co, int Tin, int Tout, int Kt, int stride, int transposed, void* ws,
+                                     size_t ws_bytes, void* stream) {
+    return wgrad_bf16(dout, in, in_scale, in_shift, in_relu, dw, db, N, Ci, Co, Tin, Tout, Kt, stride, transposed,
+                      ws, ws_bytes, stream);
 }
 
 // fp32 operands split into bf16 hi + lo, three bf16 MFMAs per product (tcn_wgrad_sw.hip, mode 2): same arguments

@@ -286,15 +286,15 @@ def tcn_wgrad(dout, inp, in_scale, in_shift, in_relu, N, Ci, Co, Tin, Tout, Kt, 
     db = torch.empty(Co, dtype=torch.float32, device=dev)
     if bf16:                                    # True / "bf16": bf16 operands; "split": fp32 operands as bf16 hi + lo
         nb = _lib.query("step_tcn_wgrad_bf16_ws_bytes", N, Ci, Co, Tin, Tout, Kt, stride)
-        if nb == 0 or (transposed and bf16 != "split"):
+        if nb == 0:
             raise _lib.StepHipError("no bf16 wgrad kernel for C=%d Kt=%d stride=%d" % (Co, Kt, stride))
         ws = _ws(nb, dev)
         if bf16 == "split":
             _lib.call("step_tcn_wgrad_split", dout, inp, in_scale, in_shift, int(in_relu), dw, db, N, Ci, Co, Tin,
                       Tout, Kt, stride, int(transposed), ws, nb)
         else:
-            _lib.call("step_tcn_wgrad_bf16", dout, inp, in_scale, in_shift, int(in_relu), dw, db, N, Ci, Co, Tin,
-                      Tout, Kt, stride, ws, nb)
+            _lib.call("step_tcn_wgrad_bf16_t", dout, inp, in_scale, in_shift, int(in_relu), dw, db, N, Ci, Co, Tin,
+                      Tout, Kt, stride, int(transposed), ws, nb)
         return dw, db
     nb = _lib.query("step_tcn_wgrad_ws_bytes", N, Ci, Co, Tin, Tout, Kt)
     ws = _ws(nb, dev)
@@ -315,7 +315,7 @@ class BlockSpec:
         # step_tcn_wgrad_split); "split_wgrad": only the weight gradient that way, the two convs on fp32 MFMAs
         split = bf16 in ("split", "split_wgrad", "split_gcn")
         conv_bf = True if bf16 is True else ("split" if bf16 in ("split", "split_gcn") else False)
-        tr_ok = (not transposed) or split       # st_gctn (ConvTranspose2d) blocks: split modes only
+        tr_ok = True        # st_gctn (ConvTranspose2d) blocks: pack modes 1 / 3, `transposed` in the weight gradients
         m0, m2 = (1, 3) if transposed else (0, 2)
         self.bf16_fwd = bool(conv_bf) and tr_ok and tcn_bf16_supported(Co, Co, Kt, stride, m0)
         self.bf16_dgrad = bool(conv_bf) and tr_ok and tcn_bf16_supported(Co, Co, Kt, stride, m2)

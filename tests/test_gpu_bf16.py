@@ -233,3 +233,60 @@ def test_bf16_real_and_synth_train_step_per_gpu_batch_512():
     assert torch.equal(out[:8], out[N - 8:])
     assert_close(out[:8], out_f32, TOL_BF16, "bf16 train logits vs fp32 oracle")
     assert _check_grads_exact(m, grads) >= 30
+
+
+def test_bf16_cvae_train_step_vs_bf16_operand_oracle():
+    """The bf16 mode on the CVAE (st_gctn blocks: ConvTranspose2d temporal convs, generator_cvae/net/CVAE_stgcn.py:340-394):
+    pack modes 1 / 3 of the bf16 conv kernels and the transposed bf16 weight gradient (step_tcn_wgrad_bf16_t).  Training
+    forward + backward of encoder -> reparameterisation (the fixture's eps) -> decoder on the reference's cvae_train
+    inputs with the shipped epoch-105 weights, against the oracle with bf16-rounded temporal-conv operands in every
+    block the kernels cover (square 32 / 64 channels; the decoder's last 3 -> 3 conv stays fp32 in both): fp32 bars.
+    And within north_star's 1e-2 of the reference's fp32 fixture."""
+    import step_amd
+    from step_amd.net.CVAE_stgcn import CVAE
+    from step_amd import ops
+    from tests.util import assert_grad_close, feeds_train_bn
+    load_npz, sub, ckpt = _load_models_helpers()
+    D = dev()
+    P = ckpt("ckpt_cvae_epoch105")
+    d = sub(load_npz("cvae_train"), "")
+    T = d["x"].shape[2]
+    keys = stgcn.trainable_keys(P)
+    leaves = {k: P[k].detach().clone().requires_grad_(True) for k in keys}
+    Q = {k: v.clone() for k, v in P.items()}
+    Q.update(leaves)
+    rec_r, mean_r, lsig_r, _ = stgcn.cvae_forward(Q, d["x"], d["lenc"], d["onehot"], d["eps"], T, 16, training=True,
+                                                  tcn_bf16=lambda c: c in (32, 64))
+    loss_r = ((rec_r - d["x"]) ** 2).mean() - 0.5 * torch.mean(1 + lsig_r - mean_r.pow(2) - lsig_r.exp())
+    gl = torch.autograd.grad(loss_r, [leaves[k] for k in keys], allow_unused=True)
+    grads = {k: g for k, g in zip(keys, gl) if g is not None}
+
+    m = CVAE(3, 75, 16, 32, 4, {"strategy": "spatial"})
+    m.load_state_dict(P)
+    m = step_amd.set_mfma_dtype(m.to(D).train(), "bf16")
+    nb = 0
+    for blk in list(m.encoder.encoder) + list(m.decoder.decoder):
+        _, co, kt, st = blk._geom
+        if co in (32, 64):
+            tr = blk.__class__.__name__ == "st_gctn"
+            assert blk.mfma_dtype == "bf16" and ops.tcn_bf16_supported(co, co, kt, st, 1 if tr else 0) \
+                and ops.tcn_bf16_supported(co, co, kt, st, 3 if tr else 2)
+            nb += 1
+    assert nb == 5
+    dd = {k: v.to(D) for k, v in d.items() if k in ("x", "lenc", "onehot", "eps")}
+    mean, lsig = m.encoder(dd["x"], dd["lenc"])
+    zz = dd["eps"] * torch.exp(0.5 * lsig) + mean
+    rec = m.decoder(zz, dd["onehot"], T, 16)
+    loss = ((rec - dd["x"]) ** 2).mean() - 0.5 * torch.mean(1 + lsig - mean.pow(2) - lsig.exp())
+    loss.backward()
+    assert abs(float(loss.detach()) - float(loss_r.detach())) < 2e-5
+    assert_close(mean, mean_r.detach(), TOL_EXACT, "bf16 CVAE mean vs bf16-operand oracle")
+    assert_close(rec, rec_r.detach(), TOL_EXACT, "bf16 CVAE reconstruction vs bf16-operand oracle")
+    n = 0
+    for k, p in m.named_parameters():
+        if k in grads:
+            assert_grad_close(p.grad, grads[k], 1e-3, k, 1e-5 if feeds_train_bn(k) else 1e-6)
+            n += 1
+    assert n >= 40
+    assert_close(mean, d["mean"], TOL_BF16, "bf16 CVAE mean vs fp32 reference")
+    assert_close(rec, d["rec"], TOL_BF16, "bf16 CVAE reconstruction vs fp32 reference")
