@@ -324,6 +324,16 @@ int step_tcn_conv_split(const float* in, const float* in_scale, const float* in_
                         int N, int Ci, int Co, int Tin, int Tout, int Kt, int stride, int pack_mode,
                         void* stream);
 
+/* step_tcn_conv_stats (train-mode forward conv that also returns SUM out, SUM out^2 per channel for the BatchNorm
+ * behind it, classifier.py:156-164) on the bf16 matrix cores: split == 0 as step_tcn_conv_bf16, else as
+ * step_tcn_conv_split; wp packed by the matching pack entry point; forward pack modes (0, 1) only.  The sums are fp32
+ * per tile and lane, fp64 from there on, in a fixed order (bit-reproducible).                                   */
+size_t step_tcn_conv_stats_bf16_ws_bytes(int Co);
+int step_tcn_conv_stats_bf16(const float* in, const float* in_scale, const float* in_shift, int in_relu,
+                             const void* wp, const float* bias, float* out,
+                             int N, int Ci, int Co, int Tin, int Tout, int Kt, int stride, int pack_mode, int split,
+                             double* sums, void* ws, size_t ws_bytes, void* stream);
+
 /* step_tcn_wgrad with every product taken as THREE bf16 MFMAs on split fp32 operands (v = hi + lo, hi = bf16(v),
  * lo = bf16(v - hi): 16 mantissa bits; a*b ~ a_lo*b_hi + a_hi*b_lo + a_hi*b_hi, fp32 accumulate; the dropped
  * lo*lo term is 2^-16 relative).  Same statement of the reference as step_tcn_wgrad (the weight part of

@@ -48,6 +48,8 @@ SIGNATURES = {
     "step_tcn_conv": (I, [P, P, P, I, P, P, P, P, P, P, P, I, P, I, I, I, I, I, I, I, I, P]),
     "step_tcn_conv_stats_ws_bytes": (Z, [I, I, I]),
     "step_tcn_conv_stats": (I, [P, P, P, I, P, P, P, I, I, I, I, I, I, I, I, P, P, Z, P]),
+    "step_tcn_conv_stats_bf16_ws_bytes": (Z, [I]),
+    "step_tcn_conv_stats_bf16": (I, [P, P, P, I, P, P, P, I, I, I, I, I, I, I, I, I, P, P, Z, P]),
     "step_tcn_const_weights": (I, [P, P, I, I, I, I, I, P]),
     "step_tcn_const_fwd": (I, [P, P, P, P, P, P, P, P, I, P, I, I, I, I, P]),
     "step_tcn_packed_bytes_bf16": (Z, [I, I, I, I, I]),

@@ -50,6 +50,7 @@ struct TbParams {
     const float* res_scale;
     const float* res_shift;
     float* out;
+    double* stat_part;   // [gridDim.x * NW][Cout][2]: SUM out, SUM out^2 per MFMA wave row (train-mode forward), or null
     int in_relu, out_relu;
     int N, Cin, Cout, Cpad, PH, Tin, Tout, R, padL, nRB, G;
 };
@@ -68,7 +69,8 @@ struct TbCfg {
     static constexpr int CHS = ((ROWS * 32 - 64 + 255) / 256) * 256 + 64;
     static constexpr int STRIP_BYTES = 16 * CHS;
     static constexpr int STAGE_BYTES = 4 * 32 * 32 * 4;       // output stages: one 32 x 32 tile per MFMA wave
-    static constexpr int LDS_BYTES = 2 * STRIP_BYTES + STAGE_BYTES;   // double-buffered strips + stages
+    static constexpr int STAT_BYTES = 4 * 64 * 8;             // per MFMA wave: [32 channels][sum | sum of squares], fp64
+    static constexpr int LDS_BYTES = 2 * STRIP_BYTES + STAGE_BYTES + STAT_BYTES;   // double-buffered strips + stages
     static constexpr int GCH = SPLIT ? 8 : 16;                // input channels of one group (one MFMA's K = 16)
     static constexpr int NBTOT = STRIDE * 2 * (NT - 1) + KT2; // B fragments of one group
     static constexpr int NB0 = STRIDE * 2 * (NT - 1) + 1;     // ... needed by tap 0
@@ -273,6 +275,12 @@ __global__ __launch_bounds__(64 * (MW * NW + NPROD)) void tcn_bf16_kernel(TbPara
         }
     };
 
+    // Batch statistics of the output for the BatchNorm behind it (train-mode forward, p.stat_part != NULL; as
+    // step_tcn_conv_stats of tcn.hip): per tile a lane sums its values in fp32 (NT x 4 per channel), the 8 lanes that
+    // share a channel row are combined by DPP row rotations and added to this wave's fp64 accumulators in LDS; after
+    // the last tile the wave writes one fp64 partial per channel into its own row for bn.hip's ordered finalize.
+    double* dacc = reinterpret_cast<double*>(smem + 2 * Cfg::STRIP_BYTES + Cfg::STAGE_BYTES) + wave * 64;
+    if (p.stat_part) dacc[lane] = 0.0;
     int it = 0;
     __syncthreads();
     for (int tile = lb; tile < ntiles; tile += gridDim.x) {
@@ -294,6 +302,7 @@ __global__ __launch_bounds__(64 * (MW * NW + NPROD)) void tcn_bf16_kernel(TbPara
         float* stg = reinterpret_cast<float*>(smem + 2 * Cfg::STRIP_BYTES) + wave * 1024;
         const int lch = lane >> 3, lq = lane & 7;
         const int fp = lq >> 2, v0 = (lq & 3) * 4;
+        float st1[4] = {0.f, 0.f, 0.f, 0.f}, st2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
 #pragma unroll
@@ -324,9 +333,34 @@ __global__ __launch_bounds__(64 * (MW * NW + NPROD)) void tcn_bf16_kernel(TbPara
                         v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
                     }
                     *reinterpret_cast<float4*>(p.out + o) = v;
+                    if (p.stat_part) {
+                        st1[k] += (v.x + v.y) + (v.z + v.w);
+                        st2[k] += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+                    }
                 }
             }
         }
+        if (p.stat_part) {
+            auto rsum8 = [](float v) {            // every lane gets the sum of its group of 8 (one channel row)
+                v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));  // row_half_mirror
+                v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+                v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+                return v;
+            };
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float a = rsum8(st1[k]), b = rsum8(st2[k]);
+                if (lq == 0) {
+                    dacc[(k * 8 + lch) * 2] += (double)a;
+                    dacc[(k * 8 + lch) * 2 + 1] += (double)b;
+                }
+            }
+        }
+    }
+    if (p.stat_part) {
+        // forward pack modes only (PH == 1: GEMM row = output channel); row of this wave: (block, column group)
+        const int c = mw * 32 + (lane >> 1);
+        if (c < p.Cout) p.stat_part[((size_t)(blockIdx.x * NW + wn) * p.Cout + c) * 2 + (lane & 1)] = dacc[lane];
     }
 }
 
@@ -371,7 +405,7 @@ bool bf16_supported(const PackGeom& g, int mode) {
 }
 
 template <int NT, int KT2, int STRIDE, int MW, int NW, bool SPLIT>
-int launch_tb(const TbParams& p, hipStream_t st) {
+int launch_tb(const TbParams& p, hipStream_t st, int* nrows) {
     using Cfg = TbCfg<NT, KT2, STRIDE, MW, NW, SPLIT>;
     TbParams q = p;
     q.nRB = step::ceil_div(p.R, Cfg::RB);
@@ -392,6 +426,13 @@ int launch_tb(const TbParams& p, hipStream_t st) {
         return STEP_ERR_LAUNCH;
     }
     const unsigned blocks = tiles < cus ? (unsigned)tiles : (unsigned)cus;   // one block per CU (LDS)
+    if (nrows) {
+        if ((int)blocks * NW > *nrows) {
+            step::set_error("step_tcn_conv_stats_bf16: %u x %d partial rows > %d", blocks, NW, *nrows);
+            return STEP_ERR_WORKSPACE;
+        }
+        *nrows = (int)blocks * NW;
+    }
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(Cfg::NTHR), Cfg::LDS_BYTES, st, q);
     return step::check_launch("step_tcn_conv_bf16");
 }
@@ -426,7 +467,8 @@ template <bool SPLIT>
 int conv(const float* in, const float* in_scale, const float* in_shift, int in_relu, const void* wp,
          const float* bias, const float* out_scale, const float* out_shift, const float* res,
          const float* res_scale, const float* res_shift, int out_relu, float* out, int N, int Ci, int Co,
-         int Tin, int Tout, int Kt, int stride, int pack_mode, void* stream) {
+         int Tin, int Tout, int Kt, int stride, int pack_mode, void* stream, double* stat_part = nullptr,
+         int* nrows = nullptr) {
     PackGeom g;
     STEP_REQUIRE(in && wp && out, "step_tcn_conv_bf16: null pointer");
     STEP_REQUIRE(N >= 1 && Ci >= 1 && Co >= 1 && Tin >= 1 && Tout >= 1,
@@ -444,6 +486,8 @@ int conv(const float* in, const float* in_scale, const float* in_shift, int in_r
     p.in = in; p.in_scale = in_scale; p.in_shift = in_shift; p.in_relu = in_relu;
     p.wp = reinterpret_cast<const bf16x8*>(wp); p.bias = bias; p.out_scale = out_scale;
     p.out_shift = out_shift; p.res = res; p.res_scale = res_scale; p.res_shift = res_shift;
+    p.stat_part = stat_part;
+    STEP_REQUIRE(!stat_part || (pack_mode < 2 && g.ph == 1), "step_tcn_conv_stats_bf16: forward pack modes only");
     p.out_relu = out_relu; p.out = out; p.N = N; p.Cin = g.cin_g; p.Cout = g.cout_g;
     p.Cpad = g.cpad; p.PH = g.ph; p.padL = g.padL; p.G = g.cin_g / (SPLIT ? 8 : 16);
     const bool dgrad = pack_mode >= 2;
@@ -454,10 +498,10 @@ int conv(const float* in, const float* in_scale, const float* in_shift, int in_r
     const int key = (2 * g.ks) * 100 + g.stride_g * 10 + mw;
     hipStream_t st = (hipStream_t)stream;
     switch (key) {
-        case 7611: return launch_tb<6, 76, 1, 1, 4, SPLIT>(p, st);
-        case 7612: return launch_tb<6, 76, 1, 2, 2, SPLIT>(p, st);
-        case 7622: return launch_tb<5, 76, 2, 2, 2, SPLIT>(p, st);
-        case 3814: return launch_tb<6, 38, 1, 4, 1, SPLIT>(p, st);
+        case 7611: return launch_tb<6, 76, 1, 1, 4, SPLIT>(p, st, nrows);
+        case 7612: return launch_tb<6, 76, 1, 2, 2, SPLIT>(p, st, nrows);
+        case 7622: return launch_tb<5, 76, 2, 2, 2, SPLIT>(p, st, nrows);
+        case 3814: return launch_tb<6, 38, 1, 4, 1, SPLIT>(p, st, nrows);
         default: break;
     }
     step::set_error("step_tcn_conv_bf16: no kernel for Kt=%d stride=%d channels=%d", Kt, stride, g.cout_g);
@@ -491,6 +535,30 @@ extern "C" int step_tcn_conv_bf16(const float* in, const float* in_scale, const 
     return conv<false>(in, in_scale, in_shift, in_relu, wp, bias, out_scale, out_shift, res, res_scale, res_shift,
                        out_relu, out, N, Ci, Co, Tin, Tout, Kt, stride, pack_mode, stream);
 }
+// step_tcn_conv_stats on the bf16 matrix cores (split == 0: bf16-rounded operands, else fp32 operands as hi + lo)
+constexpr int STAT_ROWS = 1024;         // >= blocks (one per CU) x column groups (<= 4)
+extern "C" size_t step_tcn_conv_stats_bf16_ws_bytes(int Co) {
+    return Co < 1 ? 0 : (size_t)STAT_ROWS * Co * 2 * sizeof(double);
+}
+extern "C" int step_tcn_conv_stats_bf16(const float* in, const float* in_scale, const float* in_shift, int in_relu,
+                                        const void* wp, const float* bias, float* out, int N, int Ci, int Co, int Tin,
+                                        int Tout, int Kt, int stride, int pack_mode, int split, double* sums, void* ws,
+                                        size_t ws_bytes, void* stream) {
+    STEP_REQUIRE(sums && ws, "step_tcn_conv_stats_bf16: null pointer");
+    STEP_REQUIRE(pack_mode == 0 || pack_mode == 1, "step_tcn_conv_stats_bf16: forward pack modes only (got %d)", pack_mode);
+    if (ws_bytes < step_tcn_conv_stats_bf16_ws_bytes(Co)) {
+        step::set_error("step_tcn_conv_stats_bf16: workspace %zu < %zu bytes", ws_bytes, step_tcn_conv_stats_bf16_ws_bytes(Co));
+        return STEP_ERR_WORKSPACE;
+    }
+    int rows = STAT_ROWS;
+    const int rc = split ? conv<true>(in, in_scale, in_shift, in_relu, wp, bias, nullptr, nullptr, nullptr, nullptr, nullptr, 0,
+                                      out, N, Ci, Co, Tin, Tout, Kt, stride, pack_mode, stream, (double*)ws, &rows)
+                         : conv<false>(in, in_scale, in_shift, in_relu, wp, bias, nullptr, nullptr, nullptr, nullptr, nullptr, 0,
+                                       out, N, Ci, Co, Tin, Tout, Kt, stride, pack_mode, stream, (double*)ws, &rows);
+    if (rc != STEP_OK) return rc;
+    return step::bn_sum_partials((const double*)ws, sums, Co, rows, (hipStream_t)stream);
+}
+
 extern "C" int step_tcn_conv_split(const float* in, const float* in_scale, const float* in_shift,
                                    int in_relu, const void* wp, const float* bias,
                                    const float* out_scale, const float* out_shift, const float* res,

@@ -414,13 +414,18 @@ class StGcnBlockFn(torch.autograd.Function):
         bf = s.bf16_fwd
         wp = tcn_pack(tcn_w, Co, Co, Kt, st, mode, bf16=bf)
         mr = ir = sr = hr = None
-        if training and not bf and _FUSED_STATS:
-            # train mode, fp32 kernel: SUM u, SUM u^2 per channel come out of the conv's epilogue
+        if training and _FUSED_STATS:
+            # train mode: SUM u, SUM u^2 per channel come out of the conv's epilogue
             u = torch.empty((N, Co, To, 16), dtype=torch.float32, device=dev)
             usums = torch.empty(2 * Co + 1, dtype=torch.float64, device=dev)
-            nbt = _lib.query("step_tcn_conv_stats_ws_bytes", N, Co, To)
-            _lib.call("step_tcn_conv_stats", y, s1, h1, 1, wp, tcn_b, u, N, Co, Co, T, To, Kt, st, mode,
-                      usums, _ws(nbt, dev), nbt)
+            if bf:
+                nbt = _lib.query("step_tcn_conv_stats_bf16_ws_bytes", Co)
+                _lib.call("step_tcn_conv_stats_bf16", y, s1, h1, 1, wp, tcn_b, u, N, Co, Co, T, To, Kt, st, mode,
+                          int(bf == "split"), usums, _ws(nbt, dev), nbt)
+            else:
+                nbt = _lib.query("step_tcn_conv_stats_ws_bytes", N, Co, To)
+                _lib.call("step_tcn_conv_stats", y, s1, h1, 1, wp, tcn_b, u, N, Co, Co, T, To, Kt, st, mode,
+                          usums, _ws(nbt, dev), nbt)
             synced = _sync_world() > 1
             if synced:
                 usums[2 * Co] = float(N * To * 16)

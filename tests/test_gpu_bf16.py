@@ -290,3 +290,37 @@ def test_bf16_cvae_train_step_vs_bf16_operand_oracle():
     assert n >= 40
     assert_close(mean, d["mean"], TOL_BF16, "bf16 CVAE mean vs fp32 reference")
     assert_close(rec, d["rec"], TOL_BF16, "bf16 CVAE reconstruction vs fp32 reference")
+
+
+@pytest.mark.parametrize("C,stride,T,N,tr,split", [(32, 1, 33, 3, False, 0), (64, 2, 41, 2, False, 0), (64, 1, 240, 5, False, 0),
+                                                   (64, 2, 240, 3, False, 1), (32, 1, 24, 2, True, 0), (64, 1, 75, 300, True, 1),
+                                                   (64, 1, 120, 300, False, 0)])
+def test_tcn_conv_stats_epilogue_bf16_and_split(C, stride, T, N, tr, split):
+    """step_tcn_conv_stats_bf16: u bit-equal to step_tcn_conv_bf16's / step_tcn_conv_split's, [SUM u, SUM u^2] per channel
+    equal to float64 sums of u (ragged T, stride 2, ConvTranspose packing, more tiles than blocks so that the per-wave
+    fp64 accumulators carry over tiles), bit-identical over two calls"""
+    from step_amd import _lib, ops
+    d = dev()
+    g = torch.Generator().manual_seed(C + T + N)
+    To = (T - 1) // stride + 1
+    y = torch.randn(N, C, T, 16, generator=g).to(d)
+    w = (torch.randn(C, C, 75, 1, generator=g) * 0.05).to(d)
+    b = torch.randn(C, generator=g).to(d)
+    sc, sh = (torch.rand(C, generator=g) + 0.5).to(d), torch.randn(C, generator=g).to(d) * 0.3
+    mode = 1 if tr else 0
+    bf = "split" if split else True
+    wp = ops.tcn_pack(w, C, C, 75, stride, mode, bf16=bf)
+    ref = ops.tcn_conv(y, sc, sh, True, wp, b, None, None, None, None, None, False, N, C, C, T, To, 75, stride, mode, bf16=bf)
+    nb = _lib.query("step_tcn_conv_stats_bf16_ws_bytes", C)
+    res = []
+    for _ in range(2):
+        u = torch.full((N, C, To, 16), float("nan"), device=d)
+        sums = torch.zeros(2 * C + 1, dtype=torch.float64, device=d)
+        ws = torch.empty(nb, dtype=torch.uint8, device=d)
+        _lib.call("step_tcn_conv_stats_bf16", y, sc, sh, 1, wp, b, u, N, C, C, T, To, 75, stride, mode, split, sums, ws, nb)
+        res.append((u, sums))
+    assert torch.equal(res[0][0], ref) and torch.equal(res[0][1], res[1][1])
+    ud = ref.double()
+    got = res[0][1][:2 * C].view(C, 2)
+    assert float((got[:, 0] - ud.sum(dim=(0, 2, 3))).abs().max()) <= 2e-6 * float(ud.abs().sum(dim=(0, 2, 3)).max())
+    assert float(((got[:, 1] - (ud * ud).sum(dim=(0, 2, 3))) / (ud * ud).sum(dim=(0, 2, 3))).abs().max()) <= 2e-6
