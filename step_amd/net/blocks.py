@@ -95,6 +95,7 @@ class _StBlock(nn.Module):
                          bf16={"bf16": True, "f32_split": "split", "f32_split_wgrad": "split_wgrad",
                                "f32_split_gcn": "split_gcn"}.get(self.mfma_dtype, False))
         spec.cache = self._infer_cache
+        spec.dx_skip_residual = getattr(self, "dx_skip_residual", False)     # set by saliency.GuidedBackprop only
         g = self.graph_conv.conv
         params = []
         if data_bn is not None:

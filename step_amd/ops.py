@@ -531,8 +531,14 @@ class StGcnBlockFn(torch.autograd.Function):
         nb = _lib.query("step_gcn_bwd_ws_bytes", N, Ci, Co, K, T)
         ws = _ws(nb, dev)
         idres = s.residual == "identity" and dx is not None        # dx += dout * [out > 0], in the same launch
+        res_w_dx = res_w
+        if getattr(s, "dx_skip_residual", False):
+            # saliency.GuidedBackprop: the reference's hook sits on gcn.conv, so the gradient it reports leaves the
+            # residual branch out - the kernels use the residual weight for dx only (dWr is dres x^T)
+            idres = False
+            res_w_dx = torch.zeros_like(res_w) if res_w is not None else None
         _lib.call(s.gcn_bwd, dy, dr, x, s0, h0, gcn_w, gcn_b, int(s.transposed), A_eff, s.nnz,
-                  res_w, int(s.transposed), dout if idres else None, out if idres else None,
+                  res_w_dx, int(s.transposed), dout if idres else None, out if idres else None,
                   dx, dgw, dgb, dA, drw, drb, N, Ci, Co, K, T, st, ws, nb)
 
         grads = []

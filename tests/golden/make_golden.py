@@ -611,10 +611,51 @@ def gen_affective():
     save("affective", **out)
 
 
+def gen_saliency():
+    """GuidedBackprop as the reference ships it (classifier_stgcn_real_only/utils/processor.py:17-36,98-113; its
+    `update_relus` is commented out at :28, so what `--smap` computes is the plain gradient of the target-class output
+    with respect to the input of the first graph conv's 1x1 Conv2d, taken by a backward hook on
+    `st_gcn_networks[0].gcn.conv`, model in eval mode).  processor.py itself imports h5py / torchlight, which are
+    absent here, so its hook / one-hot / backward statements are restated on the reference's own Classifier."""
+    cl = ref_import("classifier_stgcn_real_only", "classifier")
+    ck = os.path.join(REF, "classifier_stgcn_real_only", "model_classifier_stgcn", "features",
+                      "epoch395_acc81.25_model.pth.tar")
+    model = cl.Classifier(3, 4, {"strategy": "spatial"})
+    model.load_state_dict(torch.load(ck, map_location="cpu", weights_only=True))
+    model.eval()                                                            # processor.py:26
+    got = {}
+
+    def hook_function(module, grad_in, grad_out):                           # processor.py:32-33
+        got["g"] = grad_in[0]
+    first_layer = list(model._modules.items())[1][1][0].gcn.conv            # processor.py:35
+    first_layer.register_backward_hook(hook_function)                       # processor.py:36
+
+    def generate(x, target):                                                # processor.py:98-113
+        output, _ = model(x)
+        model.zero_grad()
+        one_hot = torch.zeros(output.size())
+        for idx in range(output.shape[0]):
+            one_hot[idx, target[idx]] = 1
+        output.backward(gradient=one_hot)
+        return output.detach().numpy().copy(), got["g"].detach().numpy().copy()
+
+    names, feats, labels = load_h5_gaits()
+    data = feats.reshape(feats.shape[0], feats.shape[1], 16, 3, 1)
+    data = np.moveaxis(data, [1, 2, 3], [2, 3, 1]).astype(np.float32)[:8]
+    tg = labels[:8] % 4                                              # (the file holds classes 1..4)
+    out_h5, g_h5 = generate(torch.from_numpy(data), tg)
+    torch.manual_seed(3)
+    xr = torch.randn(4, 3, 75, 16, 1) * 0.5
+    lr = np.asarray([0, 1, 2, 3], dtype=np.int64)
+    out_r, g_r = generate(xr, lr)
+    save("saliency", h5_x=data, h5_labels=tg, h5_out=out_h5, h5_grad=g_h5,
+         rnd_x=xr.numpy(), rnd_labels=lr, rnd_out=out_r, rnd_grad=g_r)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["graph", "gcn", "blocks", "ckpt", "train", "cvae", "hybrid", "vae_loss", "pose", "affective", "assemble", "trajectory"]
+    which = sys.argv[1:] or ["graph", "gcn", "blocks", "ckpt", "train", "cvae", "hybrid", "vae_loss", "pose", "affective", "assemble", "trajectory", "saliency"]
     fns = dict(graph=gen_graph, gcn=gen_gcn, blocks=gen_blocks, ckpt=gen_ckpt_and_eval,
                train=gen_train_steps, cvae=gen_cvae, hybrid=gen_hybrid, vae_loss=gen_vae_loss, pose=gen_pose_align,
-               affective=gen_affective, assemble=gen_assemble, trajectory=gen_trajectory)
+               affective=gen_affective, assemble=gen_assemble, trajectory=gen_trajectory, saliency=gen_saliency)
     for w in which:
         fns[w]()

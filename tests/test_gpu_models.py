@@ -701,3 +701,22 @@ def test_second_eval_forward_launches_no_pack_or_prepare(monkeypatch):
         del names[:]
         m(x)
     assert names.count("step_tcn_pack_weight") == 3
+
+
+def test_gradient_saliency_vs_reference_hook():
+    """`--smap` (processor.py:434-445): step_amd.saliency.GuidedBackprop against tests/golden/saliency.npz - the
+    reference's own Classifier (checkpoint 395, eval) with processor.py's hook on st_gcn_networks[0].gcn.conv and its
+    one-hot backward, on 8 shipped gaits (T = 18) and 4 random ones (T = 75): the gradient at the first graph conv's
+    input, whole batch; the call returns sample 0 as the reference does."""
+    from step_amd.net.classifier import Classifier
+    from step_amd.saliency import GuidedBackprop
+    m = _load(Classifier(3, 4, {"strategy": "spatial"}), ckpt("ckpt_classifier_real_only_epoch395"))
+    d = sub(load_npz("saliency"), "")
+    gbp = GuidedBackprop(m)
+    assert not m.training
+    for tag in ("h5", "rnd"):
+        first = gbp.generate_gradients(d[tag + "_x"].to(D), d[tag + "_labels"])
+        ref = d[tag + "_grad"]
+        assert_close(gbp.gradients, ref, 1e-3, tag + " saliency")
+        assert first.shape == tuple(ref.shape[1:])
+        assert_close(torch.from_numpy(first), ref[0], 1e-3, tag + " saliency, first sample")
