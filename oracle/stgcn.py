@@ -166,8 +166,11 @@ class _TemporalConvBf16Operands(torch.autograd.Function):
 
 
 def st_gcn_block(x, A_eff, P, prefix, stride, residual, training,
-                 transposed=False, update_running=True, return_parts=False, tcn_bf16=False):
-    """st_gcn.forward classifier.py:185-191 / st_gctn.forward CVAE_stgcn.py:388-394."""
+                 transposed=False, update_running=True, return_parts=False, tcn_bf16=False, x_res=None):
+    """st_gcn.forward classifier.py:185-191 / st_gctn.forward CVAE_stgcn.py:388-394.
+    ``x_res``: a separate tensor (same values) for the residual branch, so that a gradient can be taken through the
+    graph-conv branch alone - what a backward hook on gcn.conv sees (processor.py:31-36)."""
+    xr = x if x_res is None else x_res
     gname = "gctn" if transposed else "gcn"
     has_res_conv = (prefix + ".residual.0.weight") in P
     if not residual:
@@ -176,12 +179,12 @@ def st_gcn_block(x, A_eff, P, prefix, stride, residual, training,
         rw = P[prefix + ".residual.0.weight"]
         rb = P[prefix + ".residual.0.bias"]
         if transposed:
-            res = F.conv_transpose2d(x, rw, rb, stride=(stride, 1))
+            res = F.conv_transpose2d(xr, rw, rb, stride=(stride, 1))
         else:
-            res = F.conv2d(x, rw, rb, stride=(stride, 1))
+            res = F.conv2d(xr, rw, rb, stride=(stride, 1))
         res = bn2d(res, P, prefix + ".residual.1", training, update_running)
     else:
-        res = x
+        res = xr
     y = conv_temporal_graphical(x, A_eff, P[prefix + "." + gname + ".conv.weight"],
                                 P[prefix + "." + gname + ".conv.bias"], transposed)
     a = torch.relu(bn2d(y, P, prefix + ".tcn.0", training, update_running))

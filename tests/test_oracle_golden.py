@@ -335,3 +335,25 @@ def test_trajectory_oracle_vs_reference():
         assert abs(float(loss) - float(d["losses"][it])) <= 1e-5 * max(1.0, abs(float(d["losses"][it]))), it
         assert_close(out, d["outs"][it], 1e-4, "train-mode output of step %d" % it)
     assert trajectory_state_check(P, d) >= 55
+
+
+def test_saliency_fixture_vs_oracle():
+    """tests/golden/saliency.npz (the reference's Classifier + processor.py's backward hook on
+    st_gcn_networks[0].gcn.conv, eval mode, one-hot output gradient): the oracle's gradient at the first graph conv's
+    input through the graph-conv branch alone."""
+    P = ckpt("ckpt_classifier_real_only_epoch395")
+    d = sub(load_npz("saliency"), "")
+    for tag in ("h5", "rnd"):
+        x = d[tag + "_x"]
+        h = stgcn.data_bn(x[..., 0], P, "data_bn", False).detach().requires_grad_(True)
+        A = P["A"].to(x.dtype)
+        y = stgcn.st_gcn_block(h, A * P["edge_importance.0"], P, "st_gcn_networks.0", 1, True, False, x_res=h.detach())
+        for i, (_, _, stride, residual) in list(enumerate(stgcn.ARCH["real_only"]))[1:]:
+            y = stgcn.st_gcn_block(y, A * P["edge_importance.%d" % i], P, "st_gcn_networks.%d" % i, stride, residual, False)
+        w = P["fcn.weight"]
+        out = torch.softmax(y.mean(dim=(2, 3)) @ w.reshape(w.shape[0], -1).t() + P["fcn.bias"], dim=1)
+        assert_close(out, d[tag + "_out"], 1e-5, tag + " out")
+        one_hot = torch.zeros_like(out)
+        one_hot[torch.arange(out.shape[0]), d[tag + "_labels"].long()] = 1
+        out.backward(gradient=one_hot)
+        assert_close(h.grad, d[tag + "_grad"], 1e-4, tag + " gradient at gcn.conv's input")
