@@ -48,6 +48,16 @@ SIGNATURES = {
     "step_tcn_conv": (I, [P, P, P, I, P, P, P, P, P, P, P, I, P, I, I, I, I, I, I, I, I, P]),
     "step_tcn_conv_stats_ws_bytes": (Z, [I, I, I]),
     "step_tcn_conv_stats": (I, [P, P, P, I, P, P, P, I, I, I, I, I, I, I, I, P, P, Z, P]),
+    "step_dft_rows": (I, [I, I]),
+    "step_dft_table_stride": (I, [I]),
+    "step_dft_groups": (I, [I]),
+    "step_dft_fwd": (I, [P, P, P, I, P, P, I, I, I, I, P]),
+    "step_dft_mix": (I, [P, P, P, I, I, I, I, P]),
+    "step_dft_inv_ws_bytes": (Z, [I, I, I]),
+    "step_dft_inv": (I, [P, P, P, P, I, I, I, I, P, P, Z, P]),
+    "step_dft_wspec": (I, [P, P, P, P, P, I, I, I, I, I, P]),
+    "step_dft_wgrad_ws_bytes": (Z, [I, I, I, I]),
+    "step_dft_wgrad": (I, [P, P, P, P, P, P, I, I, I, I, I, I, P, Z, P]),
     "step_tcn_conv_stats_bf16_ws_bytes": (Z, [I]),
     "step_tcn_conv_stats_bf16": (I, [P, P, P, I, P, P, P, I, I, I, I, I, I, I, I, I, P, P, Z, P]),
     "step_tcn_const_weights": (I, [P, P, I, I, I, I, I, P]),

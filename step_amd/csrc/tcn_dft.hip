@@ -1,0 +1,614 @@
+// Temporal (Kt x 1) convolution in the frequency domain, fp32, every stage a GEMM on v_mfma_f32_32x32x2_f32.
+//
+// Same operator as step_tcn_conv / step_tcn_wgrad (tcn[2] of st_gcn / st_gctn, classifier_stgcn_real_only/net/
+// classifier.py:156-162, generator_cvae/net/CVAE_stgcn.py:359-365, and both gradients).  A 75-tap correlation along t
+// costs 75 multiply-adds per output, input and output channel; with the frames of a (sample, channel, joint) row taken
+// to L >= T + (Kt-1)/2 frequency bins the channel mixing costs 4 real multiply-adds per BIN, and the two transforms are
+// themselves small dense GEMMs against fixed cos / sin matrices (a "DFT by matmul": any T, no butterflies, exact zero
+// padding, strides and ConvTranspose are just other matrices).  For 64 channels, T = 240, stride 2 that is 4.2x fewer
+// multiply-adds than the direct kernels execute (10x at T = 120, stride 1), all of them still fp32 MFMA work.
+//
+//   r[co, tau] = SUM_ci SUM_j w[co,ci,j] a[ci, tau + j - P]      (P = (Kt-1)/2, a = 0 outside [0, T); u[t'] = r[s t'])
+//   a^[ci,f]   = SUM_t a[ci,t] e^{-2 pi i f t / L}                              step_dft_fwd   (matrix F, [2 NF x T])
+//   r^[co,f]   = SUM_ci w^[co,ci,f] a^[ci,f],  w^[f] = SUM_j w[j] e^{+2 pi i f (j-P)/L}   step_dft_mix   (per bin f)
+//   u[co,t']   = SUM_f kappa_f / L Re(r^[co,f] e^{+2 pi i f s t'/L}) + b[co]     step_dft_inv   (matrix G, [To x 2 NF])
+// L = 2 NF - 1 is odd (no Nyquist bin; kappa_0 = 1, kappa_f = 2), 2 NF = round_up(T + P + 1, 32); the circular
+// correlation equals the linear one on tau in [0, T) because L >= T + P.  Backward:
+//   du^[co,f]  = SUM_t' du[co,t'] e^{-2 pi i f s t'/L}                          step_dft_fwd   (matrix with rows at s t')
+//   da^[ci,f]  = SUM_co conj(w^[co,ci,f]) du^[co,f];  da = inverse at full rate  step_dft_mix + step_dft_inv
+//   C^[co,ci,f]= SUM_(n,v) conj(du^[co,f]) a^[ci,f]                              step_dft_wgrad (K = N * 16 per bin)
+//   dw[co,ci,j]= SUM_f kappa_f / L Re(C^[f] e^{+2 pi i f (j-P)/L});  db[co] = SUM_(n,v) Re du^[co,0]   step_dft_taps
+// Spectra live in HBM as S[n][f2][c][v] fp32, f2 = f (real part) | NF + f (imaginary part): 1.2x the size of the
+// tensor they come from; a^ of the forward pass is kept for the weight gradient.  The cos / sin matrices and the tap
+// tables are built by the host in float64 with integer-reduced angles (step_amd/dft.py) and passed in.
+#include "common.h"
+
+namespace {
+
+static __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_n(const float* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes, 0x00020000);
+}
+static __device__ __forceinline__ int rowmap(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+// ------------------------------------------------------------------------------------------------------------
+// Left-multiplication of every sample's [K x (C * 16)] matrix by a fixed [Mpad x K] matrix (stored k-major:
+// matt[k][Mpad], rows past the real extent and k past K are zero).
+//   INV == 0 (to the frequency domain): In(n,k,c,v) = act(in[n][c][k][v]),  Out = S[n][m][c][v]
+//   INV == 1 (back):                    In(n,k,c,v) = S[n][k][c][v],        Out = out[n][c][m][v] (+ bias, statistics)
+// Block = 4 waves = (sample, 8 channels = 4 column tiles of 2 channels x 16 joints, group of MG row tiles); wave w owns
+// column tile w and all MG row tiles.  The matrix streams through LDS in chunks of KC = 16 k (double-buffered, one
+// barrier per chunk); the B operand is the lane's own 4-byte load (64 contiguous bytes per 16 lanes), a chunk ahead.
+constexpr int KC = 16;
+
+struct DgParams {
+    const float* in;
+    const float* matt;       // [Kpad][Mstride], Mstride = groups * MG * 32 >= Mpad (step_dft_table_stride)
+    const float* in_scale;   // INV == 0: BN + ReLU on the load (per channel), or null
+    const float* in_shift;
+    const float* bias;       // INV == 1: per channel, or null
+    float* out;
+    double* stat_part;       // INV == 1: [N * groups][C][2] partial SUM out, SUM out^2, or null
+    int in_relu;
+    int N, C, K, Kpad, Mpad, Mrows, Mstride;
+};
+
+template <int MG, bool INV>
+__global__ __launch_bounds__(256) void dft_gemm_kernel(DgParams p) {
+    constexpr int MGR = MG * 32;
+    __shared__ __attribute__((aligned(16))) float fbuf[2][KC * MGR];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int cpar = l31 >> 4, v = l31 & 15;
+    const int groups = gridDim.x;                       // row-tile groups (fastest: they share the B operand in L2)
+    const int g = blockIdx.x;
+    const int cg = blockIdx.y, n = blockIdx.z;
+    const int c = cg * 8 + wave * 2 + cpar;
+    const int m0 = g * MGR;
+
+    // B operand addressing: descriptor on the sample, one lane offset, uniform k offsets
+    const size_t sample = (size_t)p.C * p.K * 16;
+    const __amdgpu_buffer_rsrc_t rs = rsrc_n(p.in + (size_t)n * sample, (unsigned)(sample * 4));
+    const unsigned kstride = INV ? (unsigned)p.C * 64u : 64u;                       // bytes per k
+    const unsigned voff = (INV ? (unsigned)c * 64u : (unsigned)c * (unsigned)p.K * 64u) + half * kstride + v * 4u;
+    float sc = 1.f, sh = 0.f;
+    const bool act = !INV && p.in_scale != nullptr;
+    if (act) { sc = p.in_scale[c]; sh = p.in_shift[c]; }
+    const float lo = (!INV && p.in_relu) ? 0.f : -__builtin_inff();
+
+    f32x16 acc[MG];
+#pragma unroll
+    for (int i = 0; i < MG; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    const int nchunk = p.Kpad / KC;
+    // matrix chunk: KC rows of MGR floats (row stride Mpad) -> LDS [k][MGR]; float4 items, FPT per thread
+    constexpr int F4 = KC * MGR / 4;
+    constexpr int FPT = (F4 + 255) / 256;
+    f32x4 freg[FPT];
+    auto load_f = [&](int kc) {
+#pragma unroll
+        for (int i = 0; i < FPT; ++i) {
+            const int e = tid + i * 256;
+            if (e < F4) {
+                const int kr = e / (MGR / 4), q = e - kr * (MGR / 4);
+                freg[i] = *reinterpret_cast<const f32x4*>(p.matt + (size_t)(kc * KC + kr) * p.Mstride + m0 + q * 4);
+            }
+        }
+    };
+    auto store_f = [&](int b) {
+#pragma unroll
+        for (int i = 0; i < FPT; ++i) {
+            const int e = tid + i * 256;
+            if (e < F4) *reinterpret_cast<f32x4*>(&fbuf[b][e * 4]) = freg[i];
+        }
+    };
+    float bcur[KC / 2], bnxt[KC / 2];
+    auto load_b = [&](int kc, float (&b)[KC / 2]) {
+#pragma unroll
+        for (int ks = 0; ks < KC / 2; ++ks) {
+            const int k = kc * KC + 2 * ks;                                  // (+ half: in the lane offset)
+            float x = bload(rs, voff, (unsigned)k * kstride);
+            if constexpr (!INV) {
+                if (act) x = x * sc + sh;
+                x = fmaxf(x, lo);
+                x = (k + half < p.K) ? x : 0.f;                               // k padding (the matrix rows there are 0 too)
+            }
+            b[ks] = x;
+        }
+    };
+
+    load_f(0);
+    load_b(0, bcur);
+    store_f(0);
+    __syncthreads();
+    for (int kc = 0; kc < nchunk; ++kc) {
+        const bool more = kc + 1 < nchunk;
+        if (more) { load_f(kc + 1); load_b(kc + 1, bnxt); }
+        const float* fb = fbuf[kc & 1] + half * MGR + l31;
+#pragma unroll
+        for (int ks = 0; ks < KC / 2; ++ks) {
+            float a[MG];
+#pragma unroll
+            for (int i = 0; i < MG; ++i) a[i] = fb[(2 * ks) * MGR + i * 32];
+#pragma unroll
+            for (int i = 0; i < MG; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bcur[ks], acc[i], 0, 0, 0);
+        }
+        if (more) {
+            store_f((kc + 1) & 1);
+#pragma unroll
+            for (int ks = 0; ks < KC / 2; ++ks) bcur[ks] = bnxt[ks];
+        }
+        __syncthreads();
+    }
+
+    if constexpr (!INV) {
+        // S[n][m][c][v]: 32 lanes (2 channels x 16 joints) write 128 contiguous bytes per row
+        float* o = p.out + (size_t)n * p.Mrows * p.C * 16 + (size_t)c * 16 + v;
+#pragma unroll
+        for (int i = 0; i < MG; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + i * 32 + rowmap(r, half);
+                if (m < p.Mrows) o[(size_t)m * p.C * 16] = acc[i][r];
+            }
+    } else {
+        const float bia = p.bias ? p.bias[c] : 0.f;
+        float* o = p.out + ((size_t)n * p.C + c) * p.Mrows * 16 + v;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < MG; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + i * 32 + rowmap(r, half);
+                if (m < p.Mrows) {
+                    const float x = acc[i][r] + bia;
+                    o[(size_t)m * 16] = x;
+                    s1 += x; s2 += x * x;
+                }
+            }
+        if (p.stat_part) {
+            // per (block, channel): the 16 joints by DPP row rotations, the two halves by a shuffle; fp64 from here on
+            auto rsum = [](float x) {
+                x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x128, 0xf, 0xf, true));
+                x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x124, 0xf, 0xf, true));
+                x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x122, 0xf, 0xf, true));
+                x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x121, 0xf, 0xf, true));
+                return x;
+            };
+            float a1 = rsum(s1), a2 = rsum(s2);
+            a1 += __shfl_xor(a1, 32, 64);
+            a2 += __shfl_xor(a2, 32, 64);
+            if (half == 0 && v == 0) {
+                double* d = p.stat_part + (((size_t)n * groups + g) * p.C + c) * 2;
+                d[0] = (double)a1; d[1] = (double)a2;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Channel mixing per frequency bin: Out[n][rows(f)][co][v] = Wb[f] (2 Co x 2 Ci, real block form of the complex matrix)
+// times In[n][rows(f)][ci][v].  Block = (bin, slice of the batch): Wb[f] sits in LDS (k-major), a wave takes pairs of
+// samples (32 columns = 2 samples x 16 joints) and all row tiles - waves are autonomous, no barrier in the loop.
+struct MxParams {
+    const float* in;
+    const float* wb;     // [NF][2 Ci][2 Co]
+    float* out;
+    int N, Ci, Co, NF;
+};
+
+template <int MT, int CI>        // row tiles = 2 Co / 32, input channels
+__global__ __launch_bounds__(256, 2) void dft_mix_kernel(MxParams p) {
+    extern __shared__ __attribute__((aligned(16))) float wl[];          // [2 Ci][2 Co]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int npar = l31 >> 4, v = l31 & 15;
+    const int f = blockIdx.x;
+    constexpr int K2 = 2 * CI;
+    const int M2c = 2 * p.Co;
+    const float* wsrc = p.wb + (size_t)f * K2 * M2c;
+    for (int e = tid * 4; e < K2 * M2c; e += 1024) *reinterpret_cast<f32x4*>(wl + e) = *reinterpret_cast<const f32x4*>(wsrc + e);
+    __syncthreads();
+
+    const int npairs = (p.N + 1) / 2;
+    const int per = (npairs + gridDim.y - 1) / gridDim.y;
+    const int p0 = blockIdx.y * per, p1 = min(npairs, p0 + per);
+    const int rows = 2 * p.NF;
+    const size_t in_sample = (size_t)rows * CI * 16, out_sample = (size_t)rows * p.Co * 16;
+    // lane offsets inside a sample (floats): k = 2 ks + half -> (part, ci); the two halves of a k-step are adjacent
+    // 64-byte rows, so a load instruction moves two 128-byte pieces (one per sample of the pair)
+    const unsigned in_lane = (unsigned)((f * CI + half) * 16 + v);
+    const unsigned part_jump = (unsigned)(p.NF * CI * 16);
+    const float* wa = wl + half * M2c + l31;
+
+    // all K2 / 2 operand values of a pair are requested at once, the next pair's while this one multiplies
+    float bc[CI], bn[CI];
+    auto load_pair = [&](int pr, float (&b)[CI]) {
+        int n = 2 * pr + npar;
+        n = n < p.N ? n : p.N - 1;
+        const float* src = p.in + (size_t)n * in_sample + in_lane;
+#pragma unroll
+        for (int part = 0; part < 2; ++part)
+#pragma unroll
+            for (int ks = 0; ks < CI / 2; ++ks) b[part * (CI / 2) + ks] = src[part * part_jump + ks * 32];
+    };
+    int pr = p0 + wave;
+    if (pr < p1) load_pair(pr, bc);
+    for (; pr < p1; pr += 4) {
+        if (pr + 4 < p1) load_pair(pr + 4, bn);
+        // (the W fragments are re-read from LDS for every pair: hoisted out of this loop they are 2 CI x MT registers -
+        // 256 at 64 channels - and the kernel spills at one wave per SIMD; the empty asm hides the invariance)
+        const float* wq = wa;
+        asm volatile("" : "+v"(wq));
+        f32x16 acc[MT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < CI; ++kk) {                      // k-step kk: k = 2 kk + half over the 2 CI rows of W
+            float a[MT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) a[i] = wq[(2 * kk) * M2c + i * 32];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bc[kk], acc[i], 0, 0, 0);
+        }
+        const int n = 2 * pr + npar;
+        if (n < p.N) {
+            float* dst = p.out + (size_t)n * out_sample + v;
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = i * 32 + rowmap(r, half);
+                    const int po = m >= p.Co ? 1 : 0, co = m - po * p.Co;
+                    dst[((size_t)(po * p.NF + f) * p.Co + co) * 16] = acc[i][r];
+                }
+        }
+        if (pr + 4 < p1) {
+#pragma unroll
+            for (int kk = 0; kk < CI; ++kk) bc[kk] = bn[kk];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Weight gradient per bin: P[f][split][m][k'] = SUM_(n in split, v) dS[n][row(m)][co][v] * S[n][row(k')][ci][v]
+// (m over 2 Co: real | imaginary rows of du^, k' over 2 Ci of a^).  A lane loads the 8 joints 8 half .. 8 half + 7 of its
+// row as two float4; MFMA step e pairs joint e (k = 0) with joint 8 + e (k = 1) in BOTH operands.  Block = (bin, slice);
+// its 4 waves split the (2 Co / 32) x (2 Ci / 32) tiles 2 x 2.
+struct WgParams {
+    const float* ds;     // du^  [N][2 NF][Co][16]
+    const float* s;      // a^   [N][2 NF][Ci][16]
+    float* part;         // [NF][nsplit][2 Co][2 Ci]
+    int N, Ci, Co, NF, nsplit;
+};
+
+template <int TM, int TN>     // tiles per wave
+__global__ __launch_bounds__(256) void dft_wgrad_kernel(WgParams p) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int f = blockIdx.x, split = blockIdx.y;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int n0 = (int)((long long)p.N * split / p.nsplit), n1 = (int)((long long)p.N * (split + 1) / p.nsplit);
+    const size_t ds_sample = (size_t)2 * p.NF * p.Co * 16, s_sample = (size_t)2 * p.NF * p.Ci * 16;
+    unsigned aoff[TM], boff[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = (wm * TM + i) * 32 + l31;
+        const int part = m >= p.Co ? 1 : 0, co = m - part * p.Co;
+        aoff[i] = (unsigned)(((part * p.NF + f) * p.Co + co) * 16 + 8 * half);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int k = (wn * TN + j) * 32 + l31;
+        const int part = k >= p.Ci ? 1 : 0, ci = k - part * p.Ci;
+        boff[j] = (unsigned)(((part * p.NF + f) * p.Ci + ci) * 16 + 8 * half);
+    }
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    f32x4 a[TM][2], b[TN][2], an[TM][2], bn[TN][2];
+    auto load = [&](int n, f32x4 (&x)[TM][2], f32x4 (&y)[TN][2]) {
+        const float* da = p.ds + (size_t)n * ds_sample;
+        const float* sb = p.s + (size_t)n * s_sample;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            x[i][0] = *reinterpret_cast<const f32x4*>(da + aoff[i]);
+            x[i][1] = *reinterpret_cast<const f32x4*>(da + aoff[i] + 4);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            y[j][0] = *reinterpret_cast<const f32x4*>(sb + boff[j]);
+            y[j][1] = *reinterpret_cast<const f32x4*>(sb + boff[j] + 4);
+        }
+    };
+    if (n0 < n1) load(n0, a, b);
+    for (int n = n0; n < n1; ++n) {
+        if (n + 1 < n1) load(n + 1, an, bn);
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e >> 2][e & 3], b[j][e >> 2][e & 3], acc[i][j], 0, 0, 0);
+        if (n + 1 < n1) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) { a[i][0] = an[i][0]; a[i][1] = an[i][1]; }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) { b[j][0] = bn[j][0]; b[j][1] = bn[j][1]; }
+        }
+    }
+    const int M2c = 2 * p.Co, K2 = 2 * p.Ci;
+    float* dst = p.part + ((size_t)f * p.nsplit + split) * M2c * K2;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = (wm * TM + i) * 32 + rowmap(r, half);
+                const int k = (wn * TN + j) * 32 + l31;
+                dst[(size_t)m * K2 + k] = acc[i][j][r];
+            }
+}
+
+// dw[co][ci][j] = SUM_f kap_f / L (C^r[f] tc[f][j] - C^i[f] ts[f][j]),  C^r = Prr + Pii,  C^i = Pri - Pir  (ordered sums
+// over the batch slices); db[co] = SUM_(n,v) du^[n][0][co][v] in a fixed order.  tc / ts: [NF][Kt] cos / sin of
+// 2 pi f (j - P) / L.
+__global__ __launch_bounds__(64) void dft_taps_kernel(const float* __restrict__ part, const float* __restrict__ tc,
+                                                      const float* __restrict__ ts, float* __restrict__ dw, int Ci, int Co,
+                                                      int NF, int nsplit, int Kt, int L, int transposed) {
+    const int e = blockIdx.x * 64 + threadIdx.x;
+    if (e >= Co * Ci) return;
+    const int co = e / Ci, ci = e - co * Ci;
+    const int K2 = 2 * Ci;
+    float acc[80];
+#pragma unroll
+    for (int j = 0; j < 80; ++j) acc[j] = 0.f;
+    const float inv = 1.f / (float)L;
+    for (int f = 0; f < NF; ++f) {
+        float cr = 0.f, cim = 0.f;
+        for (int s = 0; s < nsplit; ++s) {
+            const float* P = part + ((size_t)f * nsplit + s) * (2 * Co) * K2;
+            cr += P[(size_t)co * K2 + ci] + P[(size_t)(Co + co) * K2 + Ci + ci];
+            cim += P[(size_t)co * K2 + Ci + ci] - P[(size_t)(Co + co) * K2 + ci];
+        }
+        const float kap = (f == 0 ? 1.f : 2.f) * inv;
+        cr *= kap; cim *= kap;
+        const float* c = tc + (size_t)f * Kt;
+        const float* s = ts + (size_t)f * Kt;
+#pragma unroll
+        for (int j = 0; j < 80; ++j)
+            if (j < Kt) acc[j] += cr * c[j] - cim * s[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 80; ++j)
+        if (j < Kt) {
+            if (!transposed) dw[((size_t)co * Ci + ci) * Kt + j] = acc[j];
+            else dw[((size_t)ci * Co + co) * Kt + (Kt - 1 - j)] = acc[j];
+        }
+}
+
+__global__ __launch_bounds__(256) void dft_db_kernel(const float* __restrict__ ds, float* __restrict__ db, int N, int Co,
+                                                     int NF) {
+    __shared__ double red[256];
+    const int co = blockIdx.x;
+    const size_t sample = (size_t)2 * NF * Co * 16;
+    double s = 0.0;
+    for (int n = threadIdx.x; n < N; n += 256) {
+        const float* r = ds + (size_t)n * sample + (size_t)co * 16;          // row f2 = 0: SUM_t du
+        float q = 0.f;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) q += r[v];
+        s += (double)q;
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) db[co] = (float)red[0];
+}
+
+// w^[f] from the taps, as the two real block matrices the mixing kernel takes (k-major):
+//   forward  wf[f][k][m]: rows m = (part, co), columns k = (part, ci): [[Wr, -Wi], [Wi, Wr]]
+//   backward wb[f][k][m]: rows m = (part, ci), columns k = (part, co): [[Wr^T, Wi^T], [-Wi^T, Wr^T]]   (conj(w^)^T)
+__global__ __launch_bounds__(256) void dft_wspec_kernel(const float* __restrict__ w, const float* __restrict__ tc,
+                                                        const float* __restrict__ ts, float* __restrict__ wf,
+                                                        float* __restrict__ wb, int Ci, int Co, int NF, int Kt,
+                                                        int transposed) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= NF * Co * Ci) return;
+    const int ci = e % Ci, co = (e / Ci) % Co, f = e / (Ci * Co);
+    float wr = 0.f, wi = 0.f;
+    for (int j = 0; j < Kt; ++j) {
+        const float x = transposed ? w[((size_t)ci * Co + co) * Kt + (Kt - 1 - j)] : w[((size_t)co * Ci + ci) * Kt + j];
+        wr += x * tc[(size_t)f * Kt + j];
+        wi += x * ts[(size_t)f * Kt + j];
+    }
+    const int Mf = 2 * Co, Mb = 2 * Ci;
+    float* F = wf + (size_t)f * (2 * Ci) * Mf;
+    F[(size_t)ci * Mf + co] = wr;
+    F[(size_t)(Ci + ci) * Mf + co] = -wi;
+    F[(size_t)ci * Mf + Co + co] = wi;
+    F[(size_t)(Ci + ci) * Mf + Co + co] = wr;
+    float* B = wb + (size_t)f * (2 * Co) * Mb;
+    B[(size_t)co * Mb + ci] = wr;
+    B[(size_t)(Co + co) * Mb + ci] = wi;
+    B[(size_t)co * Mb + Ci + ci] = -wi;
+    B[(size_t)(Co + co) * Mb + Ci + ci] = wr;
+}
+
+int pick_mg(int mtiles) {
+    // largest group that divides the tile count, else the one with the least padding
+    const int cand[] = {9, 8, 5, 4, 3, 2};
+    for (int c : cand)
+        if (mtiles % c == 0) return c;
+    int best = 5, waste = 1 << 30;
+    for (int c : cand) {
+        const int w = step::ceil_div(mtiles, c) * c - mtiles;
+        if (w < waste) { waste = w; best = c; }
+    }
+    return best;
+}
+
+template <bool INV>
+int launch_gemm(DgParams p, hipStream_t st, const char* what) {
+    const int mtiles = p.Mpad / 32;
+    const int mg = mtiles == 1 ? 2 : pick_mg(mtiles);
+    const int groups = step::ceil_div(mtiles, mg);
+    p.Mstride = groups * mg * 32;
+    const dim3 grid((unsigned)groups, (unsigned)(p.C / 8), (unsigned)p.N);
+#define DG_CASE(MGV) case MGV: hipLaunchKernelGGL((dft_gemm_kernel<MGV, INV>), grid, dim3(256), 0, st, p); break
+    switch (mg) {
+        DG_CASE(2); DG_CASE(3); DG_CASE(4); DG_CASE(5); DG_CASE(8); DG_CASE(9);
+        default: step::set_error("%s: no kernel for %d row tiles", what, mtiles); return STEP_ERR_ARG;
+    }
+#undef DG_CASE
+    return step::check_launch(what);
+}
+
+}  // namespace
+
+// rows of a spectrum for a tensor of T frames and a Kt-tap kernel: 2 NF = round_up(T + (Kt-1)/2 + 1, 32); L = 2 NF - 1
+extern "C" int step_dft_rows(int T, int Kt) {
+    if (T < 1 || Kt < 1 || (Kt & 1) == 0) return 0;
+    return step::round_up(T + (Kt - 1) / 2 + 1, 32);
+}
+
+// row stride (floats) of the k-major matrix step_dft_fwd / step_dft_inv read for `rows` output rows: the rows padded to
+// whole groups of row tiles (columns past the real rows are zero)
+extern "C" int step_dft_table_stride(int rows) {
+    const int mtiles = step::ceil_div(rows, 32);
+    if (mtiles < 1) return 0;
+    const int mg = mtiles == 1 ? 2 : pick_mg(mtiles);
+    return step::ceil_div(mtiles, mg) * mg * 32;
+}
+
+// groups of row tiles a launch of step_dft_fwd / step_dft_inv uses for `rows` output rows (statistics partial rows
+// per sample)
+extern "C" int step_dft_groups(int rows) {
+    const int mtiles = step::ceil_div(rows, 32);
+    if (mtiles < 1) return 0;
+    const int mg = mtiles == 1 ? 2 : pick_mg(mtiles);
+    return step::ceil_div(mtiles, mg);
+}
+
+extern "C" int step_dft_fwd(const float* in, const float* in_scale, const float* in_shift, int in_relu,
+                            const float* matt, float* spec, int N, int C, int K, int rows, void* stream) {
+    STEP_REQUIRE(in && matt && spec, "step_dft_fwd: null pointer");
+    STEP_REQUIRE(N >= 1 && N <= 65535 && C >= 8 && C % 8 == 0 && C / 8 <= 65535 && K >= 1 && rows >= 32 && rows % 32 == 0,
+                 "step_dft_fwd: bad shape N=%d C=%d K=%d rows=%d", N, C, K, rows);
+    STEP_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "step_dft_fwd: scale/shift pair");
+    DgParams p{};
+    p.in = in; p.matt = matt; p.in_scale = in_scale; p.in_shift = in_shift; p.in_relu = in_relu; p.out = spec;
+    p.N = N; p.C = C; p.K = K; p.Kpad = step::round_up(K, KC); p.Mpad = rows; p.Mrows = rows;
+    return launch_gemm<false>(p, (hipStream_t)stream, "step_dft_fwd");
+}
+
+extern "C" int step_dft_inv(const float* spec, const float* matt, const float* bias, float* out, int N, int C,
+                            int rows_in, int T_out, double* sums, void* ws, size_t ws_bytes, void* stream) {
+    STEP_REQUIRE(spec && matt && out, "step_dft_inv: null pointer");
+    STEP_REQUIRE(N >= 1 && N <= 65535 && C >= 8 && C % 8 == 0 && C / 8 <= 65535 && T_out >= 1 && rows_in >= 32 && rows_in % 32 == 0,
+                 "step_dft_inv: bad shape N=%d C=%d rows=%d T=%d", N, C, rows_in, T_out);
+    DgParams p{};
+    p.in = spec; p.matt = matt; p.bias = bias; p.out = out;
+    p.N = N; p.C = C; p.K = rows_in; p.Kpad = rows_in; p.Mpad = step::round_up(T_out, 32); p.Mrows = T_out;
+    const int groups = step_dft_groups(T_out);
+    if (sums) {
+        const size_t need = (size_t)N * groups * C * 2 * sizeof(double);
+        if (!ws || ws_bytes < need) {
+            step::set_error("step_dft_inv: workspace %zu < %zu bytes", ws_bytes, need);
+            return STEP_ERR_WORKSPACE;
+        }
+        p.stat_part = (double*)ws;
+    }
+    const int rc = launch_gemm<true>(p, (hipStream_t)stream, "step_dft_inv");
+    if (rc != STEP_OK || !sums) return rc;
+    return step::bn_sum_partials((const double*)ws, sums, C, N * groups, (hipStream_t)stream);
+}
+
+extern "C" size_t step_dft_inv_ws_bytes(int N, int C, int T_out) {
+    if (N < 1 || C < 1 || T_out < 1) return 0;
+    return (size_t)N * step_dft_groups(T_out) * C * 2 * sizeof(double);
+}
+
+extern "C" int step_dft_wspec(const float* w, const float* tc, const float* ts, float* wf, float* wb, int Ci, int Co,
+                              int NF, int Kt, int transposed, void* stream) {
+    STEP_REQUIRE(w && tc && ts && wf && wb, "step_dft_wspec: null pointer");
+    STEP_REQUIRE(Ci >= 1 && Co >= 1 && NF >= 1 && Kt >= 1, "step_dft_wspec: bad shape");
+    const int total = NF * Co * Ci;
+    hipLaunchKernelGGL(dft_wspec_kernel, dim3(step::ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, w, tc, ts,
+                       wf, wb, Ci, Co, NF, Kt, transposed);
+    return step::check_launch("step_dft_wspec");
+}
+
+extern "C" int step_dft_mix(const float* in, const float* wmat, float* out, int N, int Ci, int Co, int NF, void* stream) {
+    STEP_REQUIRE(in && wmat && out, "step_dft_mix: null pointer");
+    STEP_REQUIRE(N >= 1 && (Ci == 32 || Ci == 64) && (Co == 32 || Co == 64) && NF >= 1,
+                 "step_dft_mix: unsupported N=%d Ci=%d Co=%d NF=%d", N, Ci, Co, NF);
+    MxParams p{in, wmat, out, N, Ci, Co, NF};
+    const size_t lds = (size_t)4 * Ci * Co * sizeof(float);
+    int ny = step::ceil_div(1024, NF);
+    const int npairs = (N + 1) / 2;
+    ny = ny > step::ceil_div(npairs, 4) ? step::ceil_div(npairs, 4) : ny;
+    ny = ny < 1 ? 1 : ny;
+    auto go = [&](auto kern) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            step::set_error("step_dft_mix: hipFuncSetAttribute(%zu): %s", lds, hipGetErrorString(e));
+            return (int)STEP_ERR_LAUNCH;
+        }
+        hipLaunchKernelGGL(kern, dim3((unsigned)NF, (unsigned)ny), dim3(256), lds, (hipStream_t)stream, p);
+        return step::check_launch("step_dft_mix");
+    };
+    if (Co == 64) return Ci == 64 ? go(dft_mix_kernel<4, 64>) : go(dft_mix_kernel<4, 32>);
+    return Ci == 64 ? go(dft_mix_kernel<2, 64>) : go(dft_mix_kernel<2, 32>);
+}
+
+static int wgrad_nsplit(int N, int NF) {
+    int ns = step::ceil_div(768, NF);
+    ns = ns > N ? N : ns;
+    return ns < 1 ? 1 : ns;
+}
+extern "C" size_t step_dft_wgrad_ws_bytes(int N, int Ci, int Co, int NF) {
+    if (N < 1 || Ci < 1 || Co < 1 || NF < 1) return 0;
+    return (size_t)NF * wgrad_nsplit(N, NF) * 4 * Ci * Co * sizeof(float);
+}
+
+extern "C" int step_dft_wgrad(const float* dspec, const float* spec, const float* tc, const float* ts, float* dw,
+                              float* db, int N, int Ci, int Co, int NF, int Kt, int transposed, void* ws,
+                              size_t ws_bytes, void* stream) {
+    STEP_REQUIRE(dspec && spec && tc && ts && dw && ws, "step_dft_wgrad: null pointer");
+    STEP_REQUIRE(N >= 1 && (Ci == 32 || Ci == 64) && Co == Ci && NF >= 1 && Kt >= 1 && Kt <= 80,
+                 "step_dft_wgrad: unsupported N=%d Ci=%d Co=%d NF=%d Kt=%d", N, Ci, Co, NF, Kt);
+    if (ws_bytes < step_dft_wgrad_ws_bytes(N, Ci, Co, NF)) {
+        step::set_error("step_dft_wgrad: workspace %zu < %zu bytes", ws_bytes, step_dft_wgrad_ws_bytes(N, Ci, Co, NF));
+        return STEP_ERR_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    WgParams p{dspec, spec, (float*)ws, N, Ci, Co, NF, wgrad_nsplit(N, NF)};
+    const dim3 grid((unsigned)NF, (unsigned)p.nsplit);
+    if (Co == 64) hipLaunchKernelGGL((dft_wgrad_kernel<2, 2>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((dft_wgrad_kernel<1, 1>), grid, dim3(256), 0, st, p);
+    int rc = step::check_launch("step_dft_wgrad");
+    if (rc != STEP_OK) return rc;
+    hipLaunchKernelGGL(dft_taps_kernel, dim3(step::ceil_div(Co * Ci, 64)), dim3(64), 0, st, (const float*)ws, tc, ts, dw,
+                       Ci, Co, NF, p.nsplit, Kt, 2 * NF - 1, transposed);
+    rc = step::check_launch("step_dft_wgrad(taps)");
+    if (rc != STEP_OK || !db) return rc;
+    hipLaunchKernelGGL(dft_db_kernel, dim3((unsigned)Co), dim3(256), 0, st, dspec, db, N, Co, NF);
+    return step::check_launch("step_dft_wgrad(db)");
+}

@@ -1,0 +1,136 @@
+"""Host side of the frequency-domain temporal convolution (csrc/tcn_dft.hip): the fixed cos / sin matrices, built in
+float64 with integer-reduced angles and cached per shape and device, and the three operators on top of the C ABI.
+
+Same statements of the reference as ops.tcn_conv / ops.tcn_wgrad: tcn[2] of st_gcn / st_gctn
+(classifier_stgcn_real_only/net/classifier.py:156-162, generator_cvae/net/CVAE_stgcn.py:359-365) and its gradients."""
+import math
+
+import torch
+
+from . import _lib
+
+_TABLES = {}
+
+
+def supported(C, Kt):
+    """square 32- / 64-channel temporal convs with an odd kernel of at most 79 taps (the model's: Kt = 75 and 9)"""
+    return C in (32, 64) and Kt % 2 == 1 and Kt <= 79
+
+
+def geometry(T, Kt):
+    rows = _lib.query("step_dft_rows", T, Kt)
+    return rows, rows // 2, rows - 1            # rows = 2 NF, NF, L
+
+
+def _angles(a, b, L):
+    """2 pi (a b mod L) / L for integer grids a (column) and b (row), float64"""
+    prod = torch.remainder(a.to(torch.int64)[:, None] * b.to(torch.int64)[None, :], L).to(torch.float64)
+    return prod * (2.0 * math.pi / L)
+
+
+def fwd_matrix(K, step, T, Kt, device):
+    """k-major transform matrix for K samples taken at frames step * k of a length-T grid: [round_up(K,16)][stride],
+    column f < NF: cos(2 pi f step k / L), column NF + f: -sin(...)"""
+    key = ("fwd", K, step, T, Kt, str(device))
+    if key not in _TABLES:
+        rows, NF, L = geometry(T, Kt)
+        stride = _lib.query("step_dft_table_stride", rows)
+        kpad = (K + 15) // 16 * 16
+        ang = _angles(torch.arange(K) * step, torch.arange(NF), L)          # [K][NF]
+        m = torch.zeros(kpad, stride, dtype=torch.float64)
+        m[:K, :NF] = torch.cos(ang)
+        m[:K, NF:2 * NF] = -torch.sin(ang)
+        _TABLES[key] = m.to(torch.float32).to(device).contiguous()
+    return _TABLES[key]
+
+
+def inv_matrix(T_out, step, T, Kt, device):
+    """k-major inverse matrix onto frames step * t, t < T_out: [rows][stride], row f < NF: kap_f / L cos(2 pi f step t / L),
+    row NF + f: -kap_f / L sin(...); kap_0 = 1, else 2 (L is odd: no Nyquist bin)"""
+    key = ("inv", T_out, step, T, Kt, str(device))
+    if key not in _TABLES:
+        rows, NF, L = geometry(T, Kt)
+        stride = _lib.query("step_dft_table_stride", T_out)
+        ang = _angles(torch.arange(NF), torch.arange(T_out) * step, L)      # [NF][T_out]
+        kap = torch.full((NF, 1), 2.0 / L, dtype=torch.float64)
+        kap[0, 0] = 1.0 / L
+        m = torch.zeros(rows, stride, dtype=torch.float64)
+        m[:NF, :T_out] = kap * torch.cos(ang)
+        m[NF:2 * NF, :T_out] = -kap * torch.sin(ang)
+        _TABLES[key] = m.to(torch.float32).to(device).contiguous()
+    return _TABLES[key]
+
+
+def tap_tables(T, Kt, device):
+    """tc / ts [NF][Kt]: cos / sin of 2 pi f (j - P) / L"""
+    key = ("taps", T, Kt, str(device))
+    if key not in _TABLES:
+        rows, NF, L = geometry(T, Kt)
+        ang = _angles(torch.arange(NF), torch.arange(Kt) - (Kt - 1) // 2, L)
+        _TABLES[key] = (torch.cos(ang).to(torch.float32).to(device).contiguous(),
+                        torch.sin(ang).to(torch.float32).to(device).contiguous())
+    return _TABLES[key]
+
+
+def weight_spectrum(w, C, T, Kt, transposed):
+    """(forward, backward) mixing matrices [NF][2C][2C] of the taps w (Co,Ci,Kt,1) [or (Ci,Co,Kt,1) when transposed]"""
+    rows, NF, L = geometry(T, Kt)
+    tc, ts = tap_tables(T, Kt, w.device)
+    wf = torch.empty(NF * 4 * C * C, dtype=torch.float32, device=w.device)
+    wb = torch.empty_like(wf)
+    _lib.call("step_dft_wspec", w, tc, ts, wf, wb, C, C, NF, Kt, int(transposed))
+    return wf, wb
+
+
+def transform(x, scale, shift, relu, step, T, Kt):
+    """spectrum [N][rows][C][16] of act(x) (N,C,K,16), whose K frames sit at step * k of a length-T grid"""
+    N, C, K, V = x.shape
+    rows, NF, L = geometry(T, Kt)
+    spec = torch.empty((N, rows, C, 16), dtype=torch.float32, device=x.device)
+    _lib.call("step_dft_fwd", x, scale, shift, int(relu), fwd_matrix(K, step, T, Kt, x.device), spec, N, C, K, rows)
+    return spec
+
+
+def mix(spec, wmat, C):
+    N, rows = spec.shape[0], spec.shape[1]
+    out = torch.empty_like(spec)
+    _lib.call("step_dft_mix", spec, wmat, out, N, C, C, rows // 2)
+    return out
+
+
+def inverse(spec, bias, T_out, step, T, Kt, sums=None):
+    """(N,C,T_out,16) at frames step * t of the length-T grid (+ bias); sums: float64 [2C + 1] to receive the BatchNorm
+    statistics of the result (SUM, SUM of squares per channel)"""
+    N, rows, C, V = spec.shape
+    out = torch.empty((N, C, T_out, 16), dtype=torch.float32, device=spec.device)
+    ws, nb = None, 0
+    if sums is not None:
+        nb = _lib.query("step_dft_inv_ws_bytes", N, C, T_out)
+        ws = torch.empty(nb, dtype=torch.uint8, device=spec.device)
+    _lib.call("step_dft_inv", spec, inv_matrix(T_out, step, T, Kt, spec.device), bias, out, N, C, rows, T_out, sums, ws, nb)
+    return out
+
+
+def conv_forward(y, scale, shift, relu, wf, bias, T_out, stride, Kt, sums=None):
+    """u = conv(act(y)) + bias -> (u, spectrum of act(y)); wf from weight_spectrum"""
+    N, C, T, V = y.shape
+    sa = transform(y, scale, shift, relu, 1, T, Kt)
+    u = inverse(mix(sa, wf, C), bias, T_out, stride, T, Kt, sums)
+    return u, sa
+
+
+def conv_dgrad(sdu, wb, T, Kt):
+    """gradient with respect to the activated input, (N,C,T,16), from the spectrum of dout"""
+    C = sdu.shape[2]
+    return inverse(mix(sdu, wb, C), None, T, 1, T, Kt)
+
+
+def conv_wgrad(sdu, sa, T, Kt, transposed, wshape):
+    N, rows, C, V = sa.shape
+    tc, ts = tap_tables(T, Kt, sa.device)
+    dw = torch.empty(wshape, dtype=torch.float32, device=sa.device)
+    db = torch.empty(C, dtype=torch.float32, device=sa.device)
+    nb = _lib.query("step_dft_wgrad_ws_bytes", N, C, C, rows // 2)
+    ws = torch.empty(nb, dtype=torch.uint8, device=sa.device)
+    _lib.call("step_dft_wgrad", sdu, sa, tc, ts, dw, db, N, C, C, rows // 2, Kt, int(transposed), ws, nb)
+    return dw, db

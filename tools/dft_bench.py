@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Stage timings of the frequency-domain temporal conv (step_amd/dft.py) beside the direct fp32 kernels.
+usage: python tools/dft_bench.py [--n 4096] [--c 64] [--stride 2] [--t 240] [--reps 3]"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from step_amd import dft, ops  # noqa: E402
+
+
+def timeit(fn, reps):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=4096)
+    ap.add_argument("--c", type=int, default=64)
+    ap.add_argument("--stride", type=int, default=2)
+    ap.add_argument("--t", type=int, default=240)
+    ap.add_argument("--kt", type=int, default=75)
+    ap.add_argument("--reps", type=int, default=3)
+    a = ap.parse_args()
+    d = "cuda:0"
+    n, c, s, t, kt = a.n, a.c, a.stride, a.t, a.kt
+    to = (t - 1) // s + 1
+    g = torch.Generator().manual_seed(7)
+    y = torch.randn(n, c, t, 16, generator=g).to(d)
+    du = torch.randn(n, c, to, 16, generator=g).to(d)
+    w = (torch.randn(c, c, kt, 1, generator=g) * 0.02).to(d)
+    b = torch.zeros(c, device=d)
+    sc, sh = torch.ones(c, device=d), torch.zeros(c, device=d)
+    rows, NF, L = dft.geometry(t, kt)
+    wf, wb = dft.weight_spectrum(w, c, t, kt, False)
+    sums = torch.zeros(2 * c + 1, dtype=torch.float64, device=d)
+    sa = dft.transform(y, sc, sh, True, 1, t, kt)
+    sm = dft.mix(sa, wf, c)
+    sdu = dft.transform(du, None, None, False, s, t, kt)
+    smb = dft.mix(sdu, wb, c)
+    fl = 2.0 * c * c * kt * to * 16 * n
+    stages = [
+        ("wspec", lambda: dft.weight_spectrum(w, c, t, kt, False), 0),
+        ("fwd: transform(a)", lambda: dft.transform(y, sc, sh, True, 1, t, kt), 2.0 * rows * t * c * 16 * n),
+        ("fwd: mix", lambda: dft.mix(sa, wf, c), 2.0 * 4 * c * c * 16 * NF * n),
+        ("fwd: inverse(+stats)", lambda: dft.inverse(sm, b, to, s, t, kt, sums), 2.0 * rows * to * c * 16 * n),
+        ("bwd: transform(du)", lambda: dft.transform(du, None, None, False, s, t, kt), 2.0 * rows * to * c * 16 * n),
+        ("bwd: mix", lambda: dft.mix(sdu, wb, c), 2.0 * 4 * c * c * 16 * NF * n),
+        ("bwd: inverse", lambda: dft.inverse(smb, None, t, 1, t, kt), 2.0 * rows * t * c * 16 * n),
+        ("bwd: wgrad", lambda: dft.conv_wgrad(sdu, sa, t, kt, False, tuple(w.shape)), 2.0 * 4 * c * c * 16 * NF * n),
+    ]
+    tot = {"fwd": 0.0, "bwd": 0.0}
+    print("C=%d s=%d T=%d N=%d Kt=%d: rows=%d L=%d, spectrum %.2f GB" % (c, s, t, n, kt, rows, L, sa.numel() * 4 / 1e9))
+    for name, fn, flops in stages:
+        ms = timeit(fn, a.reps)
+        if name[:3] in tot:
+            tot[name[:3]] += ms
+        print("  %-22s %8.3f ms  %7.1f TFLOP/s executed" % (name, ms, flops / ms / 1e9), flush=True)
+    print("  forward %.2f ms, backward (dgrad + wgrad) %.2f ms; direct-conv FLOPs per pass %.2f T -> %.0f / %.0f TFLOP/s equivalent"
+          % (tot["fwd"], tot["bwd"], fl / 1e12, fl / tot["fwd"] / 1e9, 2 * fl / tot["bwd"] / 1e9))
+    if kt == 75:
+        wp = ops.tcn_pack(w, c, c, kt, s, 0)
+        wpd = ops.tcn_pack(w, c, c, kt, s, 2)
+        f = timeit(lambda: ops.tcn_conv(y, sc, sh, True, wp, b, None, None, None, None, None, False, n, c, c, t, to, kt, s, 0), a.reps)
+        dg = timeit(lambda: ops.tcn_conv(du, None, None, False, wpd, None, None, None, None, None, None, False, n, c, c, t, to, kt, s, 2), a.reps)
+        wg = timeit(lambda: ops.tcn_wgrad(du, y, sc, sh, True, n, c, c, t, to, kt, s, False, w.shape), a.reps)
+        print("  direct kernels: fwd %.2f ms, dgrad %.2f ms, wgrad %.2f ms" % (f, dg, wg))
+
+
+if __name__ == "__main__":
+    main()
