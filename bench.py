@@ -295,7 +295,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-kernels", action="store_true")
     ap.add_argument("--no-infer", action="store_true")
-    ap.add_argument("--mfma", choices=["f32", "bf16", "f32_split", "f32_split_wgrad", "f32_split_gcn"], default="f32",
+    ap.add_argument("--mfma", choices=["f32", "bf16", "f32_split", "f32_split_wgrad", "f32_split_gcn", "f32_dft"], default="f32",
                     help="MFMA operand type of the temporal convs for the headline number (f32 = BASELINE "
                          "configs[1]); with f32 a short bf16-operand run is reported beside it")
     ap.add_argument("--no-bf16", action="store_true", help="skip the secondary bf16-operand run")

@@ -19,9 +19,12 @@ def set_mfma_dtype(model, dtype):
     taken as three bf16 MFMA terms with fp32 accumulation - held to the fp32 bars of the parity tests at about three
     times the fp32-MFMA kernels' speed ("f32_split_wgrad": only the weight gradient that way; "f32_split_gcn": the
     graph conv of the 32 / 64-channel blocks too, step_gcn_fwd_split / step_gcn_bwd_split).  Blocks without a
-    bf16 kernel (Kt != 75, 3 channels; st_gctn blocks in the "bf16" mode) stay fp32."""
-    if dtype not in ("f32", "bf16", "f32_split", "f32_split_wgrad", "f32_split_gcn"):
-        raise ValueError("mfma dtype must be 'f32', 'bf16', 'f32_split', 'f32_split_wgrad' or 'f32_split_gcn', got %r" % (dtype,))
+    bf16 kernel (Kt != 75, 3 channels) stay fp32.
+    "f32_dft": plain fp32 arithmetic, but the temporal conv and both its gradients in the frequency domain (transform ->
+    per-bin channel mixing -> inverse transform, all fp32 MFMA GEMMs: csrc/tcn_dft.hip) - 4-10x fewer multiply-adds than
+    the direct kernels for the 75-tap kernel; blocks it does not cover (3 channels) stay on the direct kernels."""
+    if dtype not in ("f32", "bf16", "f32_split", "f32_split_wgrad", "f32_split_gcn", "f32_dft"):
+        raise ValueError("mfma dtype must be 'f32', 'bf16', 'f32_split', 'f32_split_wgrad', 'f32_split_gcn' or 'f32_dft', got %r" % (dtype,))
     from .net.blocks import _StBlock
     for m in model.modules():
         if isinstance(m, _StBlock):

@@ -6,6 +6,7 @@ Tensor layout is (N, C, T, V=16) fp32 contiguous throughout.
 import torch
 
 from . import _lib
+from . import dft as _dft_mod
 
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
@@ -313,6 +314,11 @@ class BlockSpec:
         # bf16 MFMA operands for the temporal conv where those kernels exist (fp32 otherwise)
         # bf16 == "split": fp32 operands as bf16 hi + lo on the bf16 matrix cores (step_tcn_conv_split,
         # step_tcn_wgrad_split); "split_wgrad": only the weight gradient that way, the two convs on fp32 MFMAs
+        # bf16 == "dft": fp32 arithmetic, temporal conv and its gradients in the frequency domain (step_amd/dft.py)
+        from . import dft as _dft
+        self.dft = bf16 == "dft" and _dft.supported(Co, Kt)
+        if bf16 == "dft":
+            bf16 = False
         split = bf16 in ("split", "split_wgrad", "split_gcn")
         conv_bf = True if bf16 is True else ("split" if bf16 in ("split", "split_gcn") else False)
         tr_ok = True        # st_gctn (ConvTranspose2d) blocks: pack modes 1 / 3, `transposed` in the weight gradients
@@ -412,9 +418,30 @@ class StGcnBlockFn(torch.autograd.Function):
             m1, i1, s1, h1 = bn_prepare(y, 0, s.bn1, training)
         mode = 1 if s.transposed else 0
         bf = s.bf16_fwd
-        wp = tcn_pack(tcn_w, Co, Co, Kt, st, mode, bf16=bf)
         mr = ir = sr = hr = None
-        if training and _FUSED_STATS:
+        sa = wb_dft = None
+        if s.dft:
+            # frequency domain: the spectrum of relu(bn1(y)) is kept for the weight gradient
+            wf_dft, wb_dft = _dft_mod.weight_spectrum(tcn_w, Co, T, Kt, s.transposed)
+            usums = torch.empty(2 * Co + 1, dtype=torch.float64, device=dev) if (training and _FUSED_STATS) else None
+            u, sa = _dft_mod.conv_forward(y, s1, h1, True, wf_dft, tcn_b, To, st, Kt, usums)
+            del wf_dft
+            if not need_grad:
+                sa = wb_dft = None
+            if usums is not None:
+                synced = _sync_world() > 1
+                if synced:
+                    usums[2 * Co] = float(N * To * 16)
+                    _sync_sums(usums)
+                m2, i2, s2, h2 = bn_finalize_sums(usums, N * To * 16, s.bn2, synced)
+            else:
+                m2, i2, s2, h2 = bn_prepare(u, 0, s.bn2, training)
+            wp = None
+        else:
+            wp = tcn_pack(tcn_w, Co, Co, Kt, st, mode, bf16=bf)
+        if s.dft:
+            pass
+        elif training and _FUSED_STATS:
             # train mode: SUM u, SUM u^2 per channel come out of the conv's epilogue
             u = torch.empty((N, Co, To, 16), dtype=torch.float32, device=dev)
             usums = torch.empty(2 * Co + 1, dtype=torch.float64, device=dev)
@@ -448,7 +475,7 @@ class StGcnBlockFn(torch.autograd.Function):
             ctx.shape = (N, Ci, T, To, K)
             ctx.nparams = len(params)
             ctx.save_for_backward(x, A_eff, y, u, r, out, gcn_w, gcn_b, tcn_w, res_w, bn1_w, bn2_w, bnr_w,
-                                  dbn_w, m0, i0, s0, h0, m1, i1, s1, h1, m2, i2, s2, h2, mr, ir, sr, hr)
+                                  dbn_w, m0, i0, s0, h0, m1, i1, s1, h1, m2, i2, s2, h2, mr, ir, sr, hr, sa, wb_dft)
             ctx.x_needs_grad = ctx.needs_input_grad[2]
         return out
 
@@ -474,8 +501,6 @@ class StGcnBlockFn(torch.autograd.Function):
         s1, h1 = bn_eval_cached(c, "bn1", s.bn1)
         mode = 1 if s.transposed else 0
         bf = s.bf16_fwd
-        wp = cached(c, "wp", tensor_key(tcn_w) + (str(bf), mode, st),
-                    lambda: tcn_pack(tcn_w, Co, Co, Kt, st, mode, bf16=bf))
         s2, h2 = bn_eval_cached(c, "bn2", s.bn2)
         res_t = sr = hr = None
         if s.residual == "conv":
@@ -483,6 +508,14 @@ class StGcnBlockFn(torch.autograd.Function):
             res_t = r
         elif s.residual == "identity":
             res_t = x
+        if s.dft:
+            # frequency domain: the weights' spectrum is cached per parameter version and sequence length
+            wf_dft = cached(c, "wf_dft", tensor_key(tcn_w) + (T, int(s.transposed)),
+                            lambda: _dft_mod.weight_spectrum(tcn_w, Co, T, Kt, s.transposed)[0])
+            u, _ = _dft_mod.conv_forward(y, s1, h1, True, wf_dft, tcn_b, To, st, Kt)
+            return affine_act(u, s2, h2, res_t, sr, hr, True, 0)
+        wp = cached(c, "wp", tensor_key(tcn_w) + (str(bf), mode, st),
+                    lambda: tcn_pack(tcn_w, Co, Co, Kt, st, mode, bf16=bf))
         return tcn_conv(y, s1, h1, True, wp, tcn_b, s2, h2, res_t, sr, hr, True,
                         N, Co, Co, T, To, Kt, st, mode, bf16=bf)
 
@@ -490,7 +523,7 @@ class StGcnBlockFn(torch.autograd.Function):
     def backward(ctx, dout):
         s, training = ctx.spec, ctx.training
         (x, A_eff, y, u, r, out, gcn_w, gcn_b, tcn_w, res_w, bn1_w, bn2_w, bnr_w, dbn_w,
-         m0, i0, s0, h0, m1, i1, s1, h1, m2, i2, s2, h2, mr, ir, sr, hr) = ctx.saved_tensors
+         m0, i0, s0, h0, m1, i1, s1, h1, m2, i2, s2, h2, mr, ir, sr, hr, sa, wb_dft) = ctx.saved_tensors
         N, Ci, T, To, K = ctx.shape
         Co, Kt, st = s.Co, s.Kt, s.stride
         dout = _f32(dout)
@@ -508,13 +541,20 @@ class StGcnBlockFn(torch.autograd.Function):
             du, dg2, db2 = bn_backward(dout, u, out, None, None, 1, m2, i2, bn2_w, training, 0)
 
         # temporal conv
-        dtw, dtb = tcn_wgrad(du, y, s1, h1, True, N, Co, Co, T, To, Kt, st, s.transposed, tcn_w.shape,
-                             bf16=s.bf16_wgrad)
-        dmode = 3 if s.transposed else 2
-        wpd = tcn_pack(tcn_w, Co, Co, Kt, st, dmode, bf16=s.bf16_dgrad)
-        da = tcn_conv(du, None, None, False, wpd, None, None, None, None, None, None, False,
-                      N, Co, Co, T, To, Kt, st, dmode, bf16=s.bf16_dgrad)
-        del du
+        if s.dft:
+            sdu = _dft_mod.transform(du, None, None, False, st, T, Kt)
+            del du
+            dtw, dtb = _dft_mod.conv_wgrad(sdu, sa, T, Kt, s.transposed, tuple(tcn_w.shape))
+            da = _dft_mod.conv_dgrad(sdu, wb_dft, T, Kt)
+            del sdu
+        else:
+            dtw, dtb = tcn_wgrad(du, y, s1, h1, True, N, Co, Co, T, To, Kt, st, s.transposed, tcn_w.shape,
+                                 bf16=s.bf16_wgrad)
+            dmode = 3 if s.transposed else 2
+            wpd = tcn_pack(tcn_w, Co, Co, Kt, st, dmode, bf16=s.bf16_dgrad)
+            da = tcn_conv(du, None, None, False, wpd, None, None, None, None, None, None, False,
+                          N, Co, Co, T, To, Kt, st, dmode, bf16=s.bf16_dgrad)
+            del du
 
         # BN1 + ReLU
         dy, dg1, db1 = bn_backward(da, y, None, s1, h1, 2, m1, i1, bn1_w, training, 0)

@@ -59,7 +59,7 @@ def test_block_vs_reference_golden(fname, tag, mode):
         assert_close(y2, d["y"], 1e-4, "fused eval y")
 
 
-@pytest.mark.parametrize("mfma", ["f32", "f32_split", "f32_split_gcn"])
+@pytest.mark.parametrize("mfma", ["f32", "f32_split", "f32_split_gcn", "f32_dft"])
 def test_classifier_real_only_ckpt395_eval(mfma):
     import step_amd
     from step_amd.net.classifier import Classifier
@@ -154,7 +154,7 @@ def test_train_step_kt9_vs_reference(variant):
             assert_grad_close(v, ref1, 1e-4, k, 1e-7)
 
 
-@pytest.mark.parametrize("mfma", ["f32", "f32_split_wgrad", "f32_split", "f32_split_gcn"])
+@pytest.mark.parametrize("mfma", ["f32", "f32_split_wgrad", "f32_split", "f32_split_gcn", "f32_dft"])
 def test_train_step_kt75_ckpt395_vs_reference(mfma):
     """(f32_split_wgrad: the weight gradient's products as three bf16 MFMAs on split fp32 operands - held to the
     same bars against the reference's own gradients)"""
@@ -183,7 +183,7 @@ def test_train_step_kt75_ckpt395_vs_reference(mfma):
             assert_grad_close(sd[k[3:]], v, 1e-4, k, 1e-7)
 
 
-@pytest.mark.parametrize("mfma", ["f32", "f32_split", "f32_split_gcn"])
+@pytest.mark.parametrize("mfma", ["f32", "f32_split", "f32_split_gcn", "f32_dft"])
 def test_cvae_ckpt105_eval_and_train(mfma):
     import step_amd
     from step_amd.net.CVAE_stgcn import CVAE
@@ -244,7 +244,8 @@ def test_full_size_properties():
 
 
 @pytest.mark.parametrize("variant,N,mfma", [("real_only", 4096, "f32"), ("real_and_synth", 512, "f32"),
-                                            ("real_only", 4096, "f32_split_gcn")])
+                                            ("real_only", 4096, "f32_split_gcn"), ("real_only", 4096, "f32_dft"),
+                                            ("real_and_synth", 512, "f32_dft")])
 def test_full_size_train_step_replicated_batch(variant, N, mfma):
     """The bench workloads' own shapes in train mode (configs[1]: real_only, N=4096 x 3 x 240 x 16; configs[2]:
     real_and_synth, per-GPU batch 512): a batch made of N/8 copies of 8 gaits has the same batch statistics
@@ -356,7 +357,7 @@ def test_batched_prediction_and_feature_export():
     assert np.array_equal(one, labels[:3])
 
 
-@pytest.mark.parametrize("mfma", ["f32", "f32_split_wgrad", "f32_split", "f32_split_gcn"])
+@pytest.mark.parametrize("mfma", ["f32", "f32_split_wgrad", "f32_split", "f32_split_gcn", "f32_dft"])
 def test_five_step_trajectory_vs_reference(mfma):
     """processor.py:316-335 over several iterations: 5 x (forward, CrossEntropyLoss, backward, Adam.step) on the
     real_only Classifier (Kt = 75, N = 8, T = 75), lr 0.1 dropped to 0.01 before the 4th step (adjust_lr,
