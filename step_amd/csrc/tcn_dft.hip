@@ -199,76 +199,70 @@ struct MxParams {
     int N, Ci, Co, NF;
 };
 
+// A wave owns ONE tile of 32 output rows and keeps its slice of Wb[f] in registers (CI values per lane: no LDS, no
+// barrier); the MT waves of a row of tiles walk the same pairs of samples (32 columns = 2 samples x 16 joints), their
+// operand loads meet in the L1.  All CI operand values of a pair are requested at once, the next pair's while this one
+// multiplies.
 template <int MT, int CI>        // row tiles = 2 Co / 32, input channels
 __global__ __launch_bounds__(256, 2) void dft_mix_kernel(MxParams p) {
-    extern __shared__ __attribute__((aligned(16))) float wl[];          // [2 Ci][2 Co]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, half = lane >> 5;
     const int npar = l31 >> 4, v = l31 & 15;
     const int f = blockIdx.x;
     constexpr int K2 = 2 * CI;
+    constexpr int STREAMS = 4 / MT;                          // independent pair streams per block
+    const int mt = wave % MT, stream = wave / MT;
     const int M2c = 2 * p.Co;
-    const float* wsrc = p.wb + (size_t)f * K2 * M2c;
-    for (int e = tid * 4; e < K2 * M2c; e += 1024) *reinterpret_cast<f32x4*>(wl + e) = *reinterpret_cast<const f32x4*>(wsrc + e);
-    __syncthreads();
-
+    // A fragments: lane (half, row) holds W[row][k = 2 kk + half] for kk < CI
+    float wreg[CI];
+    {
+        const float* wsrc = p.wb + (size_t)f * K2 * M2c + (size_t)half * M2c + mt * 32 + l31;
+#pragma unroll
+        for (int kk = 0; kk < CI; ++kk) wreg[kk] = wsrc[(size_t)(2 * kk) * M2c];
+    }
     const int npairs = (p.N + 1) / 2;
     const int per = (npairs + gridDim.y - 1) / gridDim.y;
     const int p0 = blockIdx.y * per, p1 = min(npairs, p0 + per);
     const int rows = 2 * p.NF;
     const size_t in_sample = (size_t)rows * CI * 16, out_sample = (size_t)rows * p.Co * 16;
-    // lane offsets inside a sample (floats): k = 2 ks + half -> (part, ci); the two halves of a k-step are adjacent
-    // 64-byte rows, so a load instruction moves two 128-byte pieces (one per sample of the pair)
-    const unsigned in_lane = (unsigned)((f * CI + half) * 16 + v);
-    const unsigned part_jump = (unsigned)(p.NF * CI * 16);
-    const float* wa = wl + half * M2c + l31;
+    // Addresses: a buffer descriptor on the PAIR (uniform; its size covers the one or two samples that exist, so the
+    // missing half of a last odd pair loads zeros and drops its stores), 32-bit lane offsets computed once, compile-time
+    // k offsets - no per-access VALU work.
+    const unsigned in_lane = (unsigned)(npar * in_sample + (f * CI + half) * 16 + v) * 4u;
+    const unsigned part_jump = (unsigned)(p.NF * CI * 16) * 4u;
+    unsigned out_lane[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = mt * 32 + rowmap(r, half);
+        const int po = m >= p.Co ? 1 : 0, co = m - po * p.Co;
+        out_lane[r] = (unsigned)(npar * out_sample + ((size_t)(po * p.NF + f) * p.Co + co) * 16 + v) * 4u;
+    }
 
-    // all K2 / 2 operand values of a pair are requested at once, the next pair's while this one multiplies
     float bc[CI], bn[CI];
     auto load_pair = [&](int pr, float (&b)[CI]) {
-        int n = 2 * pr + npar;
-        n = n < p.N ? n : p.N - 1;
-        const float* src = p.in + (size_t)n * in_sample + in_lane;
+        const int have = min(2, p.N - 2 * pr);
+        const __amdgpu_buffer_rsrc_t rs = rsrc_n(p.in + (size_t)(2 * pr) * in_sample, (unsigned)(have * in_sample * 4));
 #pragma unroll
         for (int part = 0; part < 2; ++part)
 #pragma unroll
-            for (int ks = 0; ks < CI / 2; ++ks) b[part * (CI / 2) + ks] = src[part * part_jump + ks * 32];
+            for (int ks = 0; ks < CI / 2; ++ks)
+                b[part * (CI / 2) + ks] = bload(rs, in_lane + part * part_jump, (unsigned)(ks * 128));
     };
-    int pr = p0 + wave;
+    int pr = p0 + stream;
     if (pr < p1) load_pair(pr, bc);
-    for (; pr < p1; pr += 4) {
-        if (pr + 4 < p1) load_pair(pr + 4, bn);
-        // (the W fragments are re-read from LDS for every pair: hoisted out of this loop they are 2 CI x MT registers -
-        // 256 at 64 channels - and the kernel spills at one wave per SIMD; the empty asm hides the invariance)
-        const float* wq = wa;
-        asm volatile("" : "+v"(wq));
-        f32x16 acc[MT];
+    for (; pr < p1; pr += STREAMS) {
+        if (pr + STREAMS < p1) load_pair(pr + STREAMS, bn);
+        f32x16 acc;
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        for (int kk = 0; kk < CI; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[kk], bc[kk], acc, 0, 0, 0);
+        const int have = min(2, p.N - 2 * pr);
+        const __amdgpu_buffer_rsrc_t ro = rsrc_n(p.out + (size_t)(2 * pr) * out_sample, (unsigned)(have * out_sample * 4));
 #pragma unroll
-        for (int kk = 0; kk < CI; ++kk) {                      // k-step kk: k = 2 kk + half over the 2 CI rows of W
-            float a[MT];
-#pragma unroll
-            for (int i = 0; i < MT; ++i) a[i] = wq[(2 * kk) * M2c + i * 32];
-#pragma unroll
-            for (int i = 0; i < MT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bc[kk], acc[i], 0, 0, 0);
-        }
-        const int n = 2 * pr + npar;
-        if (n < p.N) {
-            float* dst = p.out + (size_t)n * out_sample + v;
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = i * 32 + rowmap(r, half);
-                    const int po = m >= p.Co ? 1 : 0, co = m - po * p.Co;
-                    dst[((size_t)(po * p.NF + f) * p.Co + co) * 16] = acc[i][r];
-                }
-        }
-        if (pr + 4 < p1) {
+        for (int r = 0; r < 16; ++r) bstore(ro, out_lane[r], 0u, acc[r]);
+        if (pr + STREAMS < p1) {
 #pragma unroll
             for (int kk = 0; kk < CI; ++kk) bc[kk] = bn[kk];
         }
@@ -363,29 +357,37 @@ __global__ __launch_bounds__(256) void dft_wgrad_kernel(WgParams p) {
             }
 }
 
-// dw[co][ci][j] = SUM_f kap_f / L (C^r[f] tc[f][j] - C^i[f] ts[f][j]),  C^r = Prr + Pii,  C^i = Pri - Pir  (ordered sums
-// over the batch slices); db[co] = SUM_(n,v) du^[n][0][co][v] in a fixed order.  tc / ts: [NF][Kt] cos / sin of
-// 2 pi f (j - P) / L.
-__global__ __launch_bounds__(64) void dft_taps_kernel(const float* __restrict__ part, const float* __restrict__ tc,
+// C^[f][co][ci] = kap_f / L * ordered sum over the batch slices of (Prr + Pii, Pri - Pir); then
+// dw[co][ci][j] = SUM_f (C^r[f] tc[f][j] - C^i[f] ts[f][j]);  db[co] = SUM_(n,v) du^[n][0][co][v] in a fixed order.
+// tc / ts: [NF][Kt] cos / sin of 2 pi f (j - P) / L.
+__global__ __launch_bounds__(256) void dft_cfold_kernel(const float* __restrict__ part, float* __restrict__ chat, int Ci,
+                                                        int Co, int NF, int nsplit, int L) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= NF * Co * Ci) return;
+    const int ci = e % Ci, co = (e / Ci) % Co, f = e / (Ci * Co);
+    const int K2 = 2 * Ci;
+    float cr = 0.f, cim = 0.f;
+    for (int s = 0; s < nsplit; ++s) {
+        const float* P = part + ((size_t)f * nsplit + s) * (2 * Co) * K2;
+        cr += P[(size_t)co * K2 + ci] + P[(size_t)(Co + co) * K2 + Ci + ci];
+        cim += P[(size_t)co * K2 + Ci + ci] - P[(size_t)(Co + co) * K2 + ci];
+    }
+    const float kap = (f == 0 ? 1.f : 2.f) / (float)L;
+    chat[(size_t)(2 * f) * Co * Ci + co * Ci + ci] = cr * kap;
+    chat[(size_t)(2 * f + 1) * Co * Ci + co * Ci + ci] = cim * kap;
+}
+
+__global__ __launch_bounds__(64) void dft_taps_kernel(const float* __restrict__ chat, const float* __restrict__ tc,
                                                       const float* __restrict__ ts, float* __restrict__ dw, int Ci, int Co,
-                                                      int NF, int nsplit, int Kt, int L, int transposed) {
+                                                      int NF, int Kt, int transposed) {
     const int e = blockIdx.x * 64 + threadIdx.x;
     if (e >= Co * Ci) return;
     const int co = e / Ci, ci = e - co * Ci;
-    const int K2 = 2 * Ci;
     float acc[80];
 #pragma unroll
     for (int j = 0; j < 80; ++j) acc[j] = 0.f;
-    const float inv = 1.f / (float)L;
     for (int f = 0; f < NF; ++f) {
-        float cr = 0.f, cim = 0.f;
-        for (int s = 0; s < nsplit; ++s) {
-            const float* P = part + ((size_t)f * nsplit + s) * (2 * Co) * K2;
-            cr += P[(size_t)co * K2 + ci] + P[(size_t)(Co + co) * K2 + Ci + ci];
-            cim += P[(size_t)co * K2 + Ci + ci] - P[(size_t)(Co + co) * K2 + ci];
-        }
-        const float kap = (f == 0 ? 1.f : 2.f) * inv;
-        cr *= kap; cim *= kap;
+        const float cr = chat[(size_t)(2 * f) * Co * Ci + e], cim = chat[(size_t)(2 * f + 1) * Co * Ci + e];
         const float* c = tc + (size_t)f * Kt;
         const float* s = ts + (size_t)f * Kt;
 #pragma unroll
@@ -560,22 +562,17 @@ extern "C" int step_dft_mix(const float* in, const float* wmat, float* out, int 
     STEP_REQUIRE(N >= 1 && (Ci == 32 || Ci == 64) && (Co == 32 || Co == 64) && NF >= 1,
                  "step_dft_mix: unsupported N=%d Ci=%d Co=%d NF=%d", N, Ci, Co, NF);
     MxParams p{in, wmat, out, N, Ci, Co, NF};
-    const size_t lds = (size_t)4 * Ci * Co * sizeof(float);
-    int ny = step::ceil_div(1024, NF);
+    int ny = step::ceil_div(4096, NF);                   // ~8 rounds of 2 blocks per CU: no tail to speak of
     const int npairs = (N + 1) / 2;
     ny = ny > step::ceil_div(npairs, 4) ? step::ceil_div(npairs, 4) : ny;
     ny = ny < 1 ? 1 : ny;
-    auto go = [&](auto kern) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) {
-            step::set_error("step_dft_mix: hipFuncSetAttribute(%zu): %s", lds, hipGetErrorString(e));
-            return (int)STEP_ERR_LAUNCH;
-        }
-        hipLaunchKernelGGL(kern, dim3((unsigned)NF, (unsigned)ny), dim3(256), lds, (hipStream_t)stream, p);
-        return step::check_launch("step_dft_mix");
-    };
-    if (Co == 64) return Ci == 64 ? go(dft_mix_kernel<4, 64>) : go(dft_mix_kernel<4, 32>);
-    return Ci == 64 ? go(dft_mix_kernel<2, 64>) : go(dft_mix_kernel<2, 32>);
+    const dim3 grid((unsigned)NF, (unsigned)ny);
+    hipStream_t st = (hipStream_t)stream;
+    if (Co == 64 && Ci == 64) hipLaunchKernelGGL((dft_mix_kernel<4, 64>), grid, dim3(256), 0, st, p);
+    else if (Co == 64) hipLaunchKernelGGL((dft_mix_kernel<4, 32>), grid, dim3(256), 0, st, p);
+    else if (Ci == 64) hipLaunchKernelGGL((dft_mix_kernel<2, 64>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((dft_mix_kernel<2, 32>), grid, dim3(256), 0, st, p);
+    return step::check_launch("step_dft_mix");
 }
 
 static int wgrad_nsplit(int N, int NF) {
@@ -585,7 +582,7 @@ static int wgrad_nsplit(int N, int NF) {
 }
 extern "C" size_t step_dft_wgrad_ws_bytes(int N, int Ci, int Co, int NF) {
     if (N < 1 || Ci < 1 || Co < 1 || NF < 1) return 0;
-    return (size_t)NF * wgrad_nsplit(N, NF) * 4 * Ci * Co * sizeof(float);
+    return ((size_t)NF * wgrad_nsplit(N, NF) * 4 * Ci * Co + (size_t)NF * 2 * Ci * Co) * sizeof(float);
 }
 
 extern "C" int step_dft_wgrad(const float* dspec, const float* spec, const float* tc, const float* ts, float* dw,
@@ -605,8 +602,13 @@ extern "C" int step_dft_wgrad(const float* dspec, const float* spec, const float
     else hipLaunchKernelGGL((dft_wgrad_kernel<1, 1>), grid, dim3(256), 0, st, p);
     int rc = step::check_launch("step_dft_wgrad");
     if (rc != STEP_OK) return rc;
-    hipLaunchKernelGGL(dft_taps_kernel, dim3(step::ceil_div(Co * Ci, 64)), dim3(64), 0, st, (const float*)ws, tc, ts, dw,
-                       Ci, Co, NF, p.nsplit, Kt, 2 * NF - 1, transposed);
+    float* chat = (float*)ws + (size_t)NF * p.nsplit * 4 * Ci * Co;
+    hipLaunchKernelGGL(dft_cfold_kernel, dim3(step::ceil_div(NF * Co * Ci, 256)), dim3(256), 0, st, (const float*)ws, chat,
+                       Ci, Co, NF, p.nsplit, 2 * NF - 1);
+    rc = step::check_launch("step_dft_wgrad(fold)");
+    if (rc != STEP_OK) return rc;
+    hipLaunchKernelGGL(dft_taps_kernel, dim3(step::ceil_div(Co * Ci, 64)), dim3(64), 0, st, (const float*)chat, tc, ts, dw,
+                       Ci, Co, NF, Kt, transposed);
     rc = step::check_launch("step_dft_wgrad(taps)");
     if (rc != STEP_OK || !db) return rc;
     hipLaunchKernelGGL(dft_db_kernel, dim3((unsigned)Co), dim3(256), 0, st, dspec, db, N, Co, NF);
