@@ -53,7 +53,7 @@ struct DgParams {
 };
 
 template <int MG, bool INV>
-__global__ __launch_bounds__(256) void dft_gemm_kernel(DgParams p) {
+__global__ __launch_bounds__(256, 2) void dft_gemm_kernel(DgParams p) {
     constexpr int MGR = MG * 32;
     __shared__ __attribute__((aligned(16))) float fbuf[2][KC * MGR];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -87,15 +87,18 @@ __global__ __launch_bounds__(256) void dft_gemm_kernel(DgParams p) {
     constexpr int F4 = KC * MGR / 4;
     constexpr int FPT = (F4 + 255) / 256;
     f32x4 freg[FPT];
-    auto load_f = [&](int kc) {
+    unsigned foff[FPT];                                  // this thread's items inside a chunk (floats), computed once
 #pragma unroll
-        for (int i = 0; i < FPT; ++i) {
-            const int e = tid + i * 256;
-            if (e < F4) {
-                const int kr = e / (MGR / 4), q = e - kr * (MGR / 4);
-                freg[i] = *reinterpret_cast<const f32x4*>(p.matt + (size_t)(kc * KC + kr) * p.Mstride + m0 + q * 4);
-            }
-        }
+    for (int i = 0; i < FPT; ++i) {
+        const int e = tid + i * 256;
+        const int kr = e / (MGR / 4), q = e - kr * (MGR / 4);
+        foff[i] = (unsigned)(kr * p.Mstride + m0 + q * 4);
+    }
+    auto load_f = [&](int kc) {
+        const float* src = p.matt + (size_t)kc * KC * p.Mstride;
+#pragma unroll
+        for (int i = 0; i < FPT; ++i)
+            if (tid + i * 256 < F4) freg[i] = *reinterpret_cast<const f32x4*>(src + foff[i]);
     };
     auto store_f = [&](int b) {
 #pragma unroll
@@ -145,26 +148,33 @@ __global__ __launch_bounds__(256) void dft_gemm_kernel(DgParams p) {
 
     if constexpr (!INV) {
         // S[n][m][c][v]: 32 lanes (2 channels x 16 joints) write 128 contiguous bytes per row
-        float* o = p.out + (size_t)n * p.Mrows * p.C * 16 + (size_t)c * 16 + v;
+        // (descriptor on the sample's spectrum: rows past the end - a last, partial group - fall outside and are dropped)
+        const size_t osample = (size_t)p.Mrows * p.C * 16;
+        const __amdgpu_buffer_rsrc_t ro = rsrc_n(p.out + (size_t)n * osample, (unsigned)(osample * 4));
+        const unsigned rowb = (unsigned)p.C * 64u;
+        const unsigned ol = ((unsigned)(m0 + 4 * half) * (unsigned)p.C * 16u + (unsigned)c * 16u + v) * 4u;
 #pragma unroll
         for (int i = 0; i < MG; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + i * 32 + rowmap(r, half);
-                if (m < p.Mrows) o[(size_t)m * p.C * 16] = acc[i][r];
-            }
+            for (int r = 0; r < 16; ++r)
+                bstore(ro, ol, (unsigned)(i * 32 + (r & 3) + 8 * (r >> 2)) * rowb, acc[i][r]);
     } else {
         const float bia = p.bias ? p.bias[c] : 0.f;
-        float* o = p.out + ((size_t)n * p.C + c) * p.Mrows * 16 + v;
+        // descriptor on this lane's ... no: on the sample; the lane's channel row starts at c * Mrows frames, frames past
+        // Mrows (padding rows of the last tile) must not spill into the next channel: they are masked
+        const size_t osample = (size_t)p.C * p.Mrows * 16;
+        const __amdgpu_buffer_rsrc_t ro = rsrc_n(p.out + (size_t)n * osample, (unsigned)(osample * 4));
+        const unsigned ol = ((unsigned)c * (unsigned)p.Mrows * 16u + (unsigned)(m0 + 4 * half) * 16u + v) * 4u;
+        const int mlim = p.Mrows - m0 - 4 * half;          // rows (relative to this lane's first) that exist
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < MG; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + i * 32 + rowmap(r, half);
-                if (m < p.Mrows) {
+                const int mr = i * 32 + (r & 3) + 8 * (r >> 2);
+                if (mr < mlim) {
                     const float x = acc[i][r] + bia;
-                    o[(size_t)m * 16] = x;
+                    bstore(ro, ol, (unsigned)mr * 64u, x);
                     s1 += x; s2 += x * x;
                 }
             }
@@ -455,6 +465,7 @@ __global__ __launch_bounds__(256) void dft_wspec_kernel(const float* __restrict_
 
 int pick_mg(int mtiles) {
     // largest group that divides the tile count, else the one with the least padding
+    if (mtiles == 8) return 4;          // (8 tiles as one group is 272 registers: one wave per SIMD, measured slower)
     const int cand[] = {9, 8, 5, 4, 3, 2};
     for (int c : cand)
         if (mtiles % c == 0) return c;
