@@ -356,7 +356,8 @@ int step_tcn_wgrad_split(const float* dout, const float* in,
  * matt[k][stride] with stride = step_dft_table_stride(output rows), zero past the real extents.  C % 8 == 0.
  *   step_dft_fwd   S = F . act(in)      in (N,C,K,16) [BN scale/shift + ReLU on the load], F^T = matt [round_up(K,16)][stride]
  *   step_dft_mix   out[n][.][co][v] = W[f] . in[n][.][ci][v] per bin; wmat [NF][2 Ci][2 Co] from step_dft_wspec
- *   step_dft_inv   out (N,C,T_out,16) = G . S (+ bias); optional SUM out, SUM out^2 per channel (as step_tcn_conv_stats)
+ *   step_dft_inv   out (N,C,T_out,16) = G . S (+ bias); optional SUM out, SUM out^2 per channel (as step_tcn_conv_stats),
+ *                  or step_tcn_conv's eval-mode epilogue (BN2 affine, residual with its affine, ReLU: classifier.py:189-191)
  *   step_dft_wspec taps (Co,Ci,Kt) [or the ConvTranspose2d layout] -> forward and backward mixing matrices
  *   step_dft_wgrad dw, db from the spectra of dout and of the activated input (kept from the forward pass)         */
 int step_dft_rows(int T, int Kt);
@@ -366,8 +367,11 @@ int step_dft_fwd(const float* in, const float* in_scale, const float* in_shift, 
                  const float* matt, float* spec, int N, int C, int K, int rows, void* stream);
 int step_dft_mix(const float* in, const float* wmat, float* out, int N, int Ci, int Co, int NF, void* stream);
 size_t step_dft_inv_ws_bytes(int N, int C, int T_out);
-int step_dft_inv(const float* spec, const float* matt, const float* bias, float* out, int N, int C,
-                 int rows_in, int T_out, double* sums, void* ws, size_t ws_bytes, void* stream);
+int step_dft_inv(const float* spec, const float* matt, const float* bias,
+                 const float* out_scale, const float* out_shift,
+                 const float* res, const float* res_scale, const float* res_shift, int out_relu,
+                 float* out, int N, int C, int rows_in, int T_out,
+                 double* sums, void* ws, size_t ws_bytes, void* stream);
 int step_dft_wspec(const float* w, const float* tc, const float* ts, float* wf, float* wb, int Ci, int Co,
                    int NF, int Kt, int transposed, void* stream);
 size_t step_dft_wgrad_ws_bytes(int N, int Ci, int Co, int NF);

@@ -20,11 +20,14 @@ def set_mfma_dtype(model, dtype):
     times the fp32-MFMA kernels' speed ("f32_split_wgrad": only the weight gradient that way; "f32_split_gcn": the
     graph conv of the 32 / 64-channel blocks too, step_gcn_fwd_split / step_gcn_bwd_split).  Blocks without a
     bf16 kernel (Kt != 75, 3 channels) stay fp32.
-    "f32_dft": plain fp32 arithmetic, but the temporal conv and both its gradients in the frequency domain (transform ->
-    per-bin channel mixing -> inverse transform, all fp32 MFMA GEMMs: csrc/tcn_dft.hip) - 4-10x fewer multiply-adds than
-    the direct kernels for the 75-tap kernel; blocks it does not cover (3 channels) stay on the direct kernels."""
-    if dtype not in ("f32", "bf16", "f32_split", "f32_split_wgrad", "f32_split_gcn", "f32_dft"):
-        raise ValueError("mfma dtype must be 'f32', 'bf16', 'f32_split', 'f32_split_wgrad', 'f32_split_gcn' or 'f32_dft', got %r" % (dtype,))
+    The default "f32" is plain fp32 arithmetic with the temporal conv and both its gradients taken in the frequency
+    domain (transform -> per-bin channel mixing -> inverse transform, all fp32 MFMA GEMMs: csrc/tcn_dft.hip) wherever that
+    costs under 60 % of the direct kernels' multiply-adds (the 75-tap kernel at T <= ~600: 4-10x fewer) and on the direct
+    implicit-GEMM kernels elsewhere (9 taps, T = 1024, 3 channels); "f32_direct" never leaves the direct kernels,
+    "f32_dft" takes the frequency-domain path wherever its kernels exist.  All three are held to the same fp32 bars."""
+    if dtype not in ("f32", "f32_direct", "bf16", "f32_split", "f32_split_wgrad", "f32_split_gcn", "f32_dft"):
+        raise ValueError("mfma dtype must be 'f32', 'f32_direct', 'bf16', 'f32_split', 'f32_split_wgrad', 'f32_split_gcn' or "
+                         "'f32_dft', got %r" % (dtype,))
     from .net.blocks import _StBlock
     for m in model.modules():
         if isinstance(m, _StBlock):

@@ -46,6 +46,12 @@ struct DgParams {
     const float* in_scale;   // INV == 0: BN + ReLU on the load (per channel), or null
     const float* in_shift;
     const float* bias;       // INV == 1: per channel, or null
+    const float* out_scale;  // INV == 1, eval-mode epilogue: out = relu?((acc + bias) * out_scale + out_shift + res * res_scale + res_shift)
+    const float* out_shift;
+    const float* res;        // (N, C, Mrows, 16) or null
+    const float* res_scale;
+    const float* res_shift;
+    int out_relu;
     float* out;
     double* stat_part;       // INV == 1: [N * groups][C][2] partial SUM out, SUM out^2, or null
     int in_relu;
@@ -160,10 +166,15 @@ __global__ __launch_bounds__(256, 2) void dft_gemm_kernel(DgParams p) {
                 bstore(ro, ol, (unsigned)(i * 32 + (r & 3) + 8 * (r >> 2)) * rowb, acc[i][r]);
     } else {
         const float bia = p.bias ? p.bias[c] : 0.f;
-        // descriptor on this lane's ... no: on the sample; the lane's channel row starts at c * Mrows frames, frames past
-        // Mrows (padding rows of the last tile) must not spill into the next channel: they are masked
+        float osc = 1.f, osh = 0.f, rsc = 1.f, rsh = 0.f;
+        if (p.out_scale) { osc = p.out_scale[c]; osh = p.out_shift[c]; }
+        if (p.res && p.res_scale) { rsc = p.res_scale[c]; rsh = p.res_shift[c]; }
+        const bool epi = p.out_scale != nullptr || p.res != nullptr || p.out_relu != 0;       // (uniform)
+        // descriptor on the sample; the lane's channel row starts at c * Mrows frames, frames past Mrows (padding rows
+        // of the last tile) must not spill into the next channel: they are masked
         const size_t osample = (size_t)p.C * p.Mrows * 16;
         const __amdgpu_buffer_rsrc_t ro = rsrc_n(p.out + (size_t)n * osample, (unsigned)(osample * 4));
+        const __amdgpu_buffer_rsrc_t rr = rsrc_n(p.res ? p.res + (size_t)n * osample : p.out, p.res ? (unsigned)(osample * 4) : 0u);
         const unsigned ol = ((unsigned)c * (unsigned)p.Mrows * 16u + (unsigned)(m0 + 4 * half) * 16u + v) * 4u;
         const int mlim = p.Mrows - m0 - 4 * half;          // rows (relative to this lane's first) that exist
         float s1 = 0.f, s2 = 0.f;
@@ -173,7 +184,12 @@ __global__ __launch_bounds__(256, 2) void dft_gemm_kernel(DgParams p) {
             for (int r = 0; r < 16; ++r) {
                 const int mr = i * 32 + (r & 3) + 8 * (r >> 2);
                 if (mr < mlim) {
-                    const float x = acc[i][r] + bia;
+                    float x = acc[i][r] + bia;
+                    if (epi) {
+                        x = x * osc + osh;
+                        if (p.res) x += bload(rr, ol, (unsigned)mr * 64u) * rsc + rsh;
+                        if (p.out_relu) x = fmaxf(x, 0.f);
+                    }
                     bstore(ro, ol, (unsigned)mr * 64u, x);
                     s1 += x; s2 += x * x;
                 }
@@ -531,13 +547,20 @@ extern "C" int step_dft_fwd(const float* in, const float* in_scale, const float*
     return launch_gemm<false>(p, (hipStream_t)stream, "step_dft_fwd");
 }
 
-extern "C" int step_dft_inv(const float* spec, const float* matt, const float* bias, float* out, int N, int C,
-                            int rows_in, int T_out, double* sums, void* ws, size_t ws_bytes, void* stream) {
+extern "C" int step_dft_inv(const float* spec, const float* matt, const float* bias, const float* out_scale,
+                            const float* out_shift, const float* res, const float* res_scale, const float* res_shift,
+                            int out_relu, float* out, int N, int C, int rows_in, int T_out, double* sums, void* ws,
+                            size_t ws_bytes, void* stream) {
     STEP_REQUIRE(spec && matt && out, "step_dft_inv: null pointer");
     STEP_REQUIRE(N >= 1 && N <= 65535 && C >= 8 && C % 8 == 0 && C / 8 <= 65535 && T_out >= 1 && rows_in >= 32 && rows_in % 32 == 0,
                  "step_dft_inv: bad shape N=%d C=%d rows=%d T=%d", N, C, rows_in, T_out);
     DgParams p{};
+    STEP_REQUIRE((out_scale == nullptr) == (out_shift == nullptr) && (res_scale == nullptr) == (res_shift == nullptr),
+                 "step_dft_inv: scale/shift must come in pairs");
+    STEP_REQUIRE(!sums || (!out_scale && !res && !out_relu), "step_dft_inv: statistics are of the plain conv output");
     p.in = spec; p.matt = matt; p.bias = bias; p.out = out;
+    p.out_scale = out_scale; p.out_shift = out_shift; p.res = res; p.res_scale = res_scale; p.res_shift = res_shift;
+    p.out_relu = out_relu;
     p.N = N; p.C = C; p.K = rows_in; p.Kpad = rows_in; p.Mpad = step::round_up(T_out, 32); p.Mrows = T_out;
     const int groups = step_dft_groups(T_out);
     if (sums) {

@@ -17,6 +17,18 @@ def supported(C, Kt):
     return C in (32, 64) and Kt % 2 == 1 and Kt <= 79
 
 
+def preferred(C, Kt, T, T_out):
+    """cost model for the default fp32 mode: the frequency-domain path when its multiply-adds (two transforms per pass
+    + the per-bin mixing) are under 60 % of the direct kernels' (75 taps at T <= ~600: 4-10x fewer; T = 1024 or 9 taps:
+    the direct kernels win)"""
+    if not supported(C, Kt):
+        return False
+    rows = _lib.query("step_dft_rows", T, Kt)
+    cost_dft = 2.0 * rows * (T + T_out) * C * 16 + 8.0 * C * C * 16 * (rows // 2)
+    cost_direct = 2.0 * C * C * Kt * T_out * 16
+    return cost_dft < 0.6 * cost_direct
+
+
 def geometry(T, Kt):
     rows = _lib.query("step_dft_rows", T, Kt)
     return rows, rows // 2, rows - 1            # rows = 2 NF, NF, L
@@ -98,24 +110,27 @@ def mix(spec, wmat, C):
     return out
 
 
-def inverse(spec, bias, T_out, step, T, Kt, sums=None):
+def inverse(spec, bias, T_out, step, T, Kt, sums=None, epilogue=None):
     """(N,C,T_out,16) at frames step * t of the length-T grid (+ bias); sums: float64 [2C + 1] to receive the BatchNorm
-    statistics of the result (SUM, SUM of squares per channel)"""
+    statistics of the result (SUM, SUM of squares per channel); epilogue: (out_scale, out_shift, res, res_scale,
+    res_shift, relu) - the eval-mode tail of a block"""
     N, rows, C, V = spec.shape
     out = torch.empty((N, C, T_out, 16), dtype=torch.float32, device=spec.device)
     ws, nb = None, 0
     if sums is not None:
         nb = _lib.query("step_dft_inv_ws_bytes", N, C, T_out)
         ws = torch.empty(nb, dtype=torch.uint8, device=spec.device)
-    _lib.call("step_dft_inv", spec, inv_matrix(T_out, step, T, Kt, spec.device), bias, out, N, C, rows, T_out, sums, ws, nb)
+    osc, osh, res, rsc, rsh, relu = epilogue if epilogue is not None else (None, None, None, None, None, False)
+    _lib.call("step_dft_inv", spec, inv_matrix(T_out, step, T, Kt, spec.device), bias, osc, osh, res, rsc, rsh, int(relu),
+              out, N, C, rows, T_out, sums, ws, nb)
     return out
 
 
-def conv_forward(y, scale, shift, relu, wf, bias, T_out, stride, Kt, sums=None):
+def conv_forward(y, scale, shift, relu, wf, bias, T_out, stride, Kt, sums=None, epilogue=None):
     """u = conv(act(y)) + bias -> (u, spectrum of act(y)); wf from weight_spectrum"""
     N, C, T, V = y.shape
     sa = transform(y, scale, shift, relu, 1, T, Kt)
-    u = inverse(mix(sa, wf, C), bias, T_out, stride, T, Kt, sums)
+    u = inverse(mix(sa, wf, C), bias, T_out, stride, T, Kt, sums, epilogue)
     return u, sa
 
 

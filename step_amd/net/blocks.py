@@ -93,7 +93,7 @@ class _StBlock(nn.Module):
         spec = BlockSpec(ci, co, kt, stride, self._res_kind, self.transposed, self.a_nnz_max,
                          self.tcn[0], self.tcn[3], bnr, data_bn,
                          bf16={"bf16": True, "f32_split": "split", "f32_split_wgrad": "split_wgrad",
-                               "f32_split_gcn": "split_gcn", "f32_dft": "dft"}.get(self.mfma_dtype, False))
+                               "f32_split_gcn": "split_gcn", "f32_dft": "dft", "f32": "auto_dft"}.get(self.mfma_dtype, False))
         spec.cache = self._infer_cache
         spec.dx_skip_residual = getattr(self, "dx_skip_residual", False)     # set by saliency.GuidedBackprop only
         g = self.graph_conv.conv

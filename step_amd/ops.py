@@ -316,8 +316,9 @@ class BlockSpec:
         # step_tcn_wgrad_split); "split_wgrad": only the weight gradient that way, the two convs on fp32 MFMAs
         # bf16 == "dft": fp32 arithmetic, temporal conv and its gradients in the frequency domain (step_amd/dft.py)
         from . import dft as _dft
-        self.dft = bf16 == "dft" and _dft.supported(Co, Kt)
-        if bf16 == "dft":
+        #   "dft": wherever those kernels exist; "auto_dft" (the default fp32 mode): where their cost model says they win
+        self.dft = {"dft": "force", "auto_dft": "auto"}.get(bf16, False) if _dft.supported(Co, Kt) else False
+        if bf16 in ("dft", "auto_dft"):
             bf16 = False
         split = bf16 in ("split", "split_wgrad", "split_gcn")
         conv_bf = True if bf16 is True else ("split" if bf16 in ("split", "split_gcn") else False)
@@ -420,7 +421,8 @@ class StGcnBlockFn(torch.autograd.Function):
         bf = s.bf16_fwd
         mr = ir = sr = hr = None
         sa = wb_dft = None
-        if s.dft:
+        use_dft = s.dft == "force" or (s.dft == "auto" and _dft_mod.preferred(Co, Kt, T, To))
+        if use_dft:
             # frequency domain: the spectrum of relu(bn1(y)) is kept for the weight gradient
             wf_dft, wb_dft = _dft_mod.weight_spectrum(tcn_w, Co, T, Kt, s.transposed)
             usums = torch.empty(2 * Co + 1, dtype=torch.float64, device=dev) if (training and _FUSED_STATS) else None
@@ -439,7 +441,7 @@ class StGcnBlockFn(torch.autograd.Function):
             wp = None
         else:
             wp = tcn_pack(tcn_w, Co, Co, Kt, st, mode, bf16=bf)
-        if s.dft:
+        if use_dft:
             pass
         elif training and _FUSED_STATS:
             # train mode: SUM u, SUM u^2 per channel come out of the conv's epilogue
@@ -508,12 +510,13 @@ class StGcnBlockFn(torch.autograd.Function):
             res_t = r
         elif s.residual == "identity":
             res_t = x
-        if s.dft:
+        if s.dft == "force" or (s.dft == "auto" and _dft_mod.preferred(Co, Kt, T, To)):
             # frequency domain: the weights' spectrum is cached per parameter version and sequence length
             wf_dft = cached(c, "wf_dft", tensor_key(tcn_w) + (T, int(s.transposed)),
                             lambda: _dft_mod.weight_spectrum(tcn_w, Co, T, Kt, s.transposed)[0])
-            u, _ = _dft_mod.conv_forward(y, s1, h1, True, wf_dft, tcn_b, To, st, Kt)
-            return affine_act(u, s2, h2, res_t, sr, hr, True, 0)
+            out, _ = _dft_mod.conv_forward(y, s1, h1, True, wf_dft, tcn_b, To, st, Kt,
+                                           epilogue=(s2, h2, res_t, sr, hr, True))
+            return out
         wp = cached(c, "wp", tensor_key(tcn_w) + (str(bf), mode, st),
                     lambda: tcn_pack(tcn_w, Co, Co, Kt, st, mode, bf16=bf))
         return tcn_conv(y, s1, h1, True, wp, tcn_b, s2, h2, res_t, sr, hr, True,
@@ -541,7 +544,7 @@ class StGcnBlockFn(torch.autograd.Function):
             du, dg2, db2 = bn_backward(dout, u, out, None, None, 1, m2, i2, bn2_w, training, 0)
 
         # temporal conv
-        if s.dft:
+        if sa is not None:
             sdu = _dft_mod.transform(du, None, None, False, st, T, Kt)
             del du
             dtw, dtb = _dft_mod.conv_wgrad(sdu, sa, T, Kt, s.transposed, tuple(tcn_w.shape))

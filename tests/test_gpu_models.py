@@ -20,7 +20,8 @@ def _load(module, P):
 
 @pytest.mark.parametrize("fname,tag", _block_cases())
 @pytest.mark.parametrize("mode", ["train", "eval"])
-def test_block_vs_reference_golden(fname, tag, mode):
+@pytest.mark.parametrize("impl", ["f32", "f32_direct"])       # default (frequency domain where it pays) | direct kernels
+def test_block_vs_reference_golden(fname, tag, mode, impl):
     from step_amd.net.blocks import st_gcn, st_gctn
     z = load_npz(fname)
     transposed, cin, cout, stride, residual = block_meta(tag)
@@ -31,6 +32,7 @@ def test_block_vs_reference_golden(fname, tag, mode):
     blk.load_state_dict(P0)
     blk = blk.to(D).train(mode == "train")
     blk.a_nnz_max = 4
+    blk.mfma_dtype = impl
     x = d["x"].to(D).requires_grad_(True)
     A = d["A"].to(D).requires_grad_(True)
     y, _ = blk(x, A)
@@ -59,7 +61,7 @@ def test_block_vs_reference_golden(fname, tag, mode):
         assert_close(y2, d["y"], 1e-4, "fused eval y")
 
 
-@pytest.mark.parametrize("mfma", ["f32", "f32_split", "f32_split_gcn", "f32_dft"])
+@pytest.mark.parametrize("mfma", ["f32", "f32_direct", "f32_split", "f32_split_gcn", "f32_dft"])
 def test_classifier_real_only_ckpt395_eval(mfma):
     import step_amd
     from step_amd.net.classifier import Classifier
@@ -154,7 +156,7 @@ def test_train_step_kt9_vs_reference(variant):
             assert_grad_close(v, ref1, 1e-4, k, 1e-7)
 
 
-@pytest.mark.parametrize("mfma", ["f32", "f32_split_wgrad", "f32_split", "f32_split_gcn", "f32_dft"])
+@pytest.mark.parametrize("mfma", ["f32", "f32_direct", "f32_split_wgrad", "f32_split", "f32_split_gcn", "f32_dft"])
 def test_train_step_kt75_ckpt395_vs_reference(mfma):
     """(f32_split_wgrad: the weight gradient's products as three bf16 MFMAs on split fp32 operands - held to the
     same bars against the reference's own gradients)"""
@@ -183,7 +185,7 @@ def test_train_step_kt75_ckpt395_vs_reference(mfma):
             assert_grad_close(sd[k[3:]], v, 1e-4, k, 1e-7)
 
 
-@pytest.mark.parametrize("mfma", ["f32", "f32_split", "f32_split_gcn", "f32_dft"])
+@pytest.mark.parametrize("mfma", ["f32", "f32_direct", "f32_split", "f32_split_gcn", "f32_dft"])
 def test_cvae_ckpt105_eval_and_train(mfma):
     import step_amd
     from step_amd.net.CVAE_stgcn import CVAE
@@ -244,8 +246,8 @@ def test_full_size_properties():
 
 
 @pytest.mark.parametrize("variant,N,mfma", [("real_only", 4096, "f32"), ("real_and_synth", 512, "f32"),
-                                            ("real_only", 4096, "f32_split_gcn"), ("real_only", 4096, "f32_dft"),
-                                            ("real_and_synth", 512, "f32_dft")])
+                                            ("real_only", 4096, "f32_split_gcn"), ("real_only", 4096, "f32_direct"),
+                                            ("real_and_synth", 512, "f32_direct")])
 def test_full_size_train_step_replicated_batch(variant, N, mfma):
     """The bench workloads' own shapes in train mode (configs[1]: real_only, N=4096 x 3 x 240 x 16; configs[2]:
     real_and_synth, per-GPU batch 512): a batch made of N/8 copies of 8 gaits has the same batch statistics
@@ -357,7 +359,7 @@ def test_batched_prediction_and_feature_export():
     assert np.array_equal(one, labels[:3])
 
 
-@pytest.mark.parametrize("mfma", ["f32", "f32_split_wgrad", "f32_split", "f32_split_gcn", "f32_dft"])
+@pytest.mark.parametrize("mfma", ["f32", "f32_direct", "f32_split_wgrad", "f32_split", "f32_split_gcn", "f32_dft"])
 def test_five_step_trajectory_vs_reference(mfma):
     """processor.py:316-335 over several iterations: 5 x (forward, CrossEntropyLoss, backward, Adam.step) on the
     real_only Classifier (Kt = 75, N = 8, T = 75), lr 0.1 dropped to 0.01 before the 4th step (adjust_lr,
@@ -515,15 +517,18 @@ def test_wide_st_gcn_block_vs_oracle(cin, cout, stride, T, N, mode):
         assert_close(y2, yo, 1e-4, "fused eval y")
 
 
-def test_eval_under_no_grad_takes_the_fused_epilogue(monkeypatch):
+@pytest.mark.parametrize("mfma", ["f32", "f32_direct"])
+def test_eval_under_no_grad_takes_the_fused_epilogue(monkeypatch, mfma):
     """Eval-mode blocks under torch.no_grad() finish inside the temporal conv's epilogue (BN2 + residual + ReLU,
-    classifier.py:189-191) although the parameters require grad; with autograd recording they keep the separate
-    pass.  (ctx.needs_input_grad mirrors requires_grad whatever the grad mode is - this path once never ran.)"""
+    classifier.py:189-191; the direct kernel's, or the inverse transform's in the frequency-domain default) although
+    the parameters require grad; with autograd recording they keep the separate pass.  (ctx.needs_input_grad mirrors
+    requires_grad whatever the grad mode is - this path once never ran.)"""
+    import step_amd
     from step_amd import ops
     from step_amd.net.classifier import Classifier
     m = Classifier(3, 4, {"strategy": "spatial"})
     m.load_state_dict(ckpt("ckpt_classifier_real_only_epoch395"))
-    m = m.to(D).eval()
+    m = step_amd.set_mfma_dtype(m.to(D).eval(), mfma)
     x = torch.randn(3, 3, 75, 16, 1, generator=torch.Generator().manual_seed(3)).to(D)
     calls = []
     real = ops.affine_act
@@ -656,15 +661,20 @@ def test_epoch_level_caller_train_save_reload_eval(tmp_path):
         assert torch.equal(live, a)
 
 
-def test_second_eval_forward_launches_no_pack_or_prepare(monkeypatch):
+@pytest.mark.parametrize("mfma", ["f32", "f32_direct"])
+def test_second_eval_forward_launches_no_pack_or_prepare(monkeypatch, mfma):
     """Inference host path (the reference's batch-1 prediction loop, processor.py:457-473): packed temporal weights,
     eval-mode BatchNorm coefficients and A * importance are cached per parameter version, pooling + fcn + softmax are
-    one launch.  Second no-grad eval forward: 2 launches per block + 1 head, none of them a pack / prepare kernel;
-    an in-place parameter update or train() refreshes the caches."""
+    one launch.  Second no-grad eval forward: 2 launches per block + 1 head (4 per block in the frequency-domain
+    default: graph conv, transform, mixing, inverse transform with the block's tail in its epilogue), none of them a
+    pack / weight-spectrum / prepare kernel; an in-place parameter update or train() refreshes the caches."""
+    import step_amd
     from step_amd import _lib
     from step_amd.net.classifier import Classifier
     P = ckpt("ckpt_classifier_real_only_epoch395")
-    m = _load(Classifier(3, 4, {"strategy": "spatial"}), P).eval()
+    m = step_amd.set_mfma_dtype(_load(Classifier(3, 4, {"strategy": "spatial"}), P).eval(), mfma)
+    pack = "step_dft_wspec" if mfma == "f32" else "step_tcn_pack_weight"
+    conv = ["step_dft_fwd", "step_dft_mix", "step_dft_inv"] if mfma == "f32" else ["step_tcn_conv"]
     x = torch.randn(3, 3, 75, 16, 1, generator=torch.Generator().manual_seed(3)).to(D)
     names = []
     real = _lib.call
@@ -674,8 +684,8 @@ def test_second_eval_forward_launches_no_pack_or_prepare(monkeypatch):
         first = list(names)
         del names[:]
         o2, f2 = m(x)
-    assert any(n.startswith("step_tcn_pack_weight") for n in first) and "step_bn_eval_prepare" in first
-    assert sorted(names) == sorted(["step_gcn_fwd", "step_tcn_conv"] * 3 + ["step_head_fwd"]), names
+    assert any(n.startswith(pack) for n in first) and "step_bn_eval_prepare" in first
+    assert sorted(names) == sorted((["step_gcn_fwd"] + conv) * 3 + ["step_head_fwd"]), names
     assert torch.equal(o1, o2) and torch.equal(f1, f2)
     ref, rfeat = stgcn.classifier_forward({k: v.clone() for k, v in P.items()}, x.cpu(), "real_only")
     assert_close(o2, ref, 1e-4, "cached eval probs")
@@ -691,7 +701,7 @@ def test_second_eval_forward_launches_no_pack_or_prepare(monkeypatch):
         m.edge_importance[0].mul_(0.5)
         del names[:]
         o4, _ = m(x)
-    assert names.count("step_tcn_pack_weight") == 1 and names.count("step_bn_eval_prepare") == 1
+    assert names.count(pack) == 1 and names.count("step_bn_eval_prepare") == 1
     P2 = {k: v.clone() for k, v in m.state_dict().items()}
     ref4, _ = stgcn.classifier_forward({k: v.cpu() for k, v in P2.items()}, x.cpu(), "real_only")
     assert_close(o4, ref4, 1e-4, "after in-place parameter updates")
@@ -701,7 +711,7 @@ def test_second_eval_forward_launches_no_pack_or_prepare(monkeypatch):
     with torch.no_grad():
         del names[:]
         m(x)
-    assert names.count("step_tcn_pack_weight") == 3
+    assert names.count(pack) == 3
 
 
 def test_gradient_saliency_vs_reference_hook():
