@@ -108,6 +108,57 @@ def time_kernels(n, t, device, reps=3, bf16=False, blocks=None, tag="b"):
     return out
 
 
+def time_dft_kernels(n, t, device, reps=3):
+    """HIP-event timing of every stage of the frequency-domain temporal conv (the default fp32 path; step_amd/dft.py,
+    csrc/tcn_dft.hip) for the three blocks of the step, each with the FLOPs its GEMM executes:
+    transform / inverse 2 * rows * frames * C * 16 per sequence, mixing and weight gradient 2 * (2C)^2 * 16 * NF."""
+    from step_amd import dft
+    out = []
+    g = torch.Generator().manual_seed(11)
+    for bi, (c, s, tin) in enumerate([(32, 1, t), (64, 2, t), (64, 1, (t - 1) // 2 + 1)]):
+        tout = (tin - 1) // s + 1
+        rows, nf, L = dft.geometry(tin, 75)
+        y = torch.randn(n, c, tin, 16, generator=g).to(device)
+        du = torch.randn(n, c, tout, 16, generator=g).to(device)
+        w = (torch.randn(c, c, 75, 1, generator=g) * 0.02).to(device)
+        b = torch.zeros(c, device=device)
+        sc, sh = torch.ones(c, device=device), torch.zeros(c, device=device)
+        wf, wb = dft.weight_spectrum(w, c, tin, 75, False)
+        sums = torch.zeros(2 * c + 1, dtype=torch.float64, device=device)
+        sa = dft.transform(y, sc, sh, True, 1, tin, 75)
+        sm = dft.mix(sa, wf, c)
+        sdu = dft.transform(du, None, None, False, s, tin, 75)
+        smb = dft.mix(sdu, wb, c)
+        fmix = 2.0 * 4 * c * c * 16 * nf * n
+        spec_bytes = 4.0 * sa.numel()
+        stages = [
+            ("dft_transform", lambda: dft.transform(y, sc, sh, True, 1, tin, 75), 2.0 * rows * tin * c * 16 * n, 4.0 * y.numel() + spec_bytes),
+            ("dft_mix", lambda: dft.mix(sa, wf, c), fmix, 2 * spec_bytes),
+            ("dft_inverse", lambda: dft.inverse(sm, b, tout, s, tin, 75, sums), 2.0 * rows * tout * c * 16 * n, spec_bytes + 4.0 * du.numel()),
+            ("dft_transform_dout", lambda: dft.transform(du, None, None, False, s, tin, 75), 2.0 * rows * tout * c * 16 * n, 4.0 * du.numel() + spec_bytes),
+            ("dft_mix_bwd", lambda: dft.mix(sdu, wb, c), fmix, 2 * spec_bytes),
+            ("dft_inverse_bwd", lambda: dft.inverse(smb, None, tin, 1, tin, 75), 2.0 * rows * tin * c * 16 * n, spec_bytes + 4.0 * y.numel()),
+            ("dft_wgrad", lambda: dft.conv_wgrad(sdu, sa, tin, 75, False, tuple(w.shape)), fmix, 2 * spec_bytes),
+        ]
+        for name, fn, fl, nbytes in stages:
+            fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / reps
+            out.append({"kernel": "%s_b%d" % (name, bi), "C": c, "stride": s, "T_in": tin, "rows": rows, "ms": round(ms, 3),
+                        "tflops": round(fl / ms / 1e9, 2), "frac": round(fl / ms / 1e9 / PEAK_FP32_MFMA_TFLOPS, 4),
+                        "flops_per_launch": fl, "gbs": round(nbytes / ms / 1e6, 1),
+                        "frac_hbm": round(nbytes / ms / 1e6 / PEAK_HBM_GBS, 4)})
+        del y, du, sa, sm, sdu, smb
+        torch.cuda.empty_cache()
+    return out
+
+
 def time_hbm_kernels(n, t, device, reps=3):
     """HIP-event timing of the HBM-bound stages of each block (graph conv fwd / bwd, BN statistics,
     BN+residual+ReLU apply, BN backward), with their algorithmic bytes (each tensor read or written
@@ -225,6 +276,25 @@ def cpu_baseline(t, kt=75, n=192):
                       "path would run its convolutions through oneDNN" % (n, t, dt)}
 
 
+def model_flops_per_sequence_dft(t, kt=75, k=3):
+    """forward FLOPs of one sequence as the DEFAULT fp32 path executes them: the temporal conv as transform + mixing +
+    inverse transform (see time_dft_kernels), the rest as in model_flops_per_sequence; second value: fwd + bwd
+    (forward + transform of dout + mixing + full-rate inverse + weight-gradient GEMM + 2x the graph conv)"""
+    from step_amd import dft
+    fwd, both, ci, tt = 0.0, 0.0, 3, t
+    for co, s in ((32, 1), (64, 2), (64, 1)):
+        to = (tt - 1) // s + 1
+        rows, nf, _ = dft.geometry(tt, kt)
+        gcn = 2.0 * ci * k * co * tt * 16 + 2.0 * k * co * tt * 16 * 16 + (2.0 * ci * co * to * 16 if (ci != co or s != 1) else 0.0)
+        mixf = 2.0 * 4 * co * co * 16 * nf
+        f = 2.0 * rows * tt * co * 16 + mixf + 2.0 * rows * to * co * 16
+        b = 2.0 * rows * to * co * 16 + mixf + 2.0 * rows * tt * co * 16 + mixf
+        fwd += gcn + f
+        both += 3.0 * gcn + f + b
+        ci, tt = co, to
+    return fwd, both
+
+
 def model_flops_per_sequence(t, kt=75, k=3):
     """algorithmic forward FLOPs of one sequence through the real_only stack (SURVEY 8d formulas):
     gcn 2*Ci*K*Co*T*V, dense aggregation 2*K*Co*T*V^2, tcn 2*Co^2*Kt*To*V, residual conv 2*Ci*Co*To*V"""
@@ -295,7 +365,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-kernels", action="store_true")
     ap.add_argument("--no-infer", action="store_true")
-    ap.add_argument("--mfma", choices=["f32", "bf16", "f32_split", "f32_split_wgrad", "f32_split_gcn", "f32_dft"], default="f32",
+    ap.add_argument("--mfma", choices=["f32", "f32_direct", "bf16", "f32_split", "f32_split_wgrad", "f32_split_gcn", "f32_dft"], default="f32",
                     help="MFMA operand type of the temporal convs for the headline number (f32 = BASELINE "
                          "configs[1]); with f32 a short bf16-operand run is reported beside it")
     ap.add_argument("--no-bf16", action="store_true", help="skip the secondary bf16-operand run")
@@ -400,6 +470,19 @@ def main():
                 model.train()
         step_amd.set_mfma_dtype(model, "f32")
 
+    # the same fp32 step on the DIRECT implicit-GEMM temporal kernels (what the headline ran until round 3)
+    direct_run = None
+    if args.mfma == "f32" and not args.no_bf16:
+        step_amd.set_mfma_dtype(model, "f32_direct")
+        k = min(3, args.steps)
+        dtd = timed(1, k)
+        direct_run = {"mode": "f32_direct", "sequences_per_s": round(args.batch * world * k / dtd, 1),
+                      "ms_per_step": round(dtd / k * 1e3, 2), "steps": k,
+                      "step_tflops_per_gpu": round(3.0 * model_flops_per_sequence(args.frames) * args.batch * k / dtd / 1e12, 2),
+                      "note": "same model, tensors and arithmetic type; the temporal conv and its gradients as direct "
+                              "implicit GEMMs (75 multiply-adds per output and channel pair) instead of in the frequency domain"}
+        step_amd.set_mfma_dtype(model, "f32")
+
     # forward-only (eval, fused epilogues) rate of the same tensor, for reference
     infer = 0.0
     model.eval()
@@ -418,8 +501,15 @@ def main():
         del x
         torch.cuda.empty_cache()
         kernels = time_kernels(args.batch, args.frames, device, bf16=(args.mfma == "bf16"))
-        dom = max(kernels, key=lambda k: k["ms"])
+        dom_direct = max(kernels, key=lambda k: k["ms"])
+        dom = dom_direct
         torch.cuda.empty_cache()
+        if args.mfma in ("f32", "f32_dft"):
+            # the default fp32 step runs the frequency-domain stages: its dominant kernel is one of those
+            kd = time_dft_kernels(args.batch, args.frames, device)
+            dom = max(kd, key=lambda k: k["ms"])
+            kernels = kd + kernels
+            torch.cuda.empty_cache()
         kernels = kernels + time_hbm_kernels(args.batch, args.frames, device)
         if args.mfma == "f32":          # MFMA utilisation of the wide layers (kernel-level bench points, N = batch / 2)
             torch.cuda.empty_cache()
@@ -439,10 +529,16 @@ def main():
             torch.cuda.empty_cache()
         traffic, traffic_src = (pmc_traffic(dom["kernel"], args.batch, args.frames) if args.mfma == "f32"
                                 else (None, None))
+        direct_flops = tcn_flops(args.batch, dom_direct["C"], (args.frames - 1) // 2 + 1
+                                 if dom_direct["kernel"].endswith(("b1", "b2")) else args.frames)
         roof = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"],
                 "peak": PEAK_BF16_MFMA_TFLOPS if args.mfma == "bf16" else PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": dom["frac"], "traffic": traffic, "traffic_source": traffic_src,
-                "flops_per_launch": tcn_flops(args.batch, dom["C"], (args.frames - 1) // 2 + 1
-                                              if dom["kernel"].endswith(("b1", "b2")) else args.frames)}
+                "flops_per_launch": dom.get("flops_per_launch", direct_flops)}
+        if direct_run is not None:
+            td, tsd = pmc_traffic(dom_direct["kernel"], args.batch, args.frames)
+            direct_run["roofline"] = {"bound": "mfma", "kernel": dom_direct["kernel"], "achieved": dom_direct["tflops"],
+                                      "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": dom_direct["frac"],
+                                      "traffic": td, "traffic_source": tsd, "flops_per_launch": direct_flops}
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu:       # CPU baseline: rank 0 at N=1 only
         cpu = cpu_baseline(args.frames)
@@ -452,22 +548,29 @@ def main():
             "metric": "ST-GCN fwd+bwd sequences/sec", "value": round(seq_per_s, 1), "unit": "sequences/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": args.mfma, "data": "synthetic",
+            "vs_baseline": None, "dtype": {"f32_dft": "f32", "f32_direct": "f32"}.get(args.mfma, args.mfma), "data": "synthetic",
             "config": {"workload": "configs[1] tensor: real_only ST-GCN classifier (Kt=75, 3->32->64->64), "
                                    "N=%d x 3 x %d x 16 per GPU, fp32 tensors%s; step = train-mode fwd + "
                                    "CrossEntropy + bwd + grad all-reduce + Adam"
                                    % (args.batch, args.frames,
-                                      {"bf16": ", bf16 MFMA operands in the temporal convs",
+                                      {"f32": ", fp32 arithmetic (temporal convs in the frequency domain: fp32 MFMA GEMMs)",
+                                       "f32_dft": ", fp32 arithmetic (temporal convs in the frequency domain: fp32 MFMA GEMMs)",
+                                       "f32_direct": ", fp32 arithmetic (direct implicit-GEMM temporal convs)",
+                                       "bf16": ", bf16 MFMA operands in the temporal convs",
                                        "f32_split": ", fp32 operands as bf16 hi + lo on the bf16 matrix cores",
                                        "f32_split_gcn": ", fp32 operands as bf16 hi + lo on the bf16 matrix cores (graph-conv forward too)",
                                        "f32_split_wgrad": ", wgrad operands as bf16 hi + lo"}.get(args.mfma, "")),
                        "global_batch": args.batch * world, "frames": args.frames,
                        "parallelism": "dp%d%s" % (world, "+syncbn" if args.sync_bn and world > 1 else "")},
             "inference_sequences_per_s_per_gpu": round(infer, 1),
-            "step_tflops_per_gpu": round(3.0 * model_flops_per_sequence(args.frames) * args.batch * args.steps / dt / 1e12, 2),
+            # FLOPs the step EXECUTES (frequency-domain temporal convs in the default mode); the direct-conv count of the
+            # same operators is kept beside it - it exceeds the MFMA peak by construction, 4-10x fewer multiply-adds run
+            "step_tflops_per_gpu": round((model_flops_per_sequence_dft(args.frames)[1] if args.mfma in ("f32", "f32_dft")
+                                          else 3.0 * model_flops_per_sequence(args.frames)) * args.batch * args.steps / dt / 1e12, 2),
+            "direct_conv_equivalent_tflops_per_gpu": round(3.0 * model_flops_per_sequence(args.frames) * args.batch * args.steps / dt / 1e12, 2),
             "rehearsal": ("%d ranks share one GPU, collectives over gloo through host memory: not a scaling number"
                           % world) if os.environ.get("STEP_BENCH_REHEARSAL") else None,
-            "bf16_mfma": bf16_run, "f32_split_operands": split_run, "roofline": roof, "kernels": kernels, "cpu_baseline": cpu,
+            "f32_direct": direct_run, "bf16_mfma": bf16_run, "f32_split_operands": split_run, "roofline": roof, "kernels": kernels, "cpu_baseline": cpu,
         }
         print(json.dumps(line))
     if world > 1:
