@@ -42,7 +42,7 @@ constexpr int KC = 16;
 
 struct DgParams {
     const float* in;
-    const float* matt;       // [Kpad][Mstride], Mstride = groups * MG * 32 >= Mpad (step_dft_table_stride)
+    const float* matt;       // [groups][Kpad][32][MGP]: element (g, k, l, i) = M[row g * MG * 32 + i * 32 + l][k] (step_dft_table_geom)
     const float* in_scale;   // INV == 0: BN + ReLU on the load (per channel), or null
     const float* in_shift;
     const float* bias;       // INV == 1: per channel, or null
@@ -55,13 +55,18 @@ struct DgParams {
     float* out;
     double* stat_part;       // INV == 1: [N * groups][C][2] partial SUM out, SUM out^2, or null
     int in_relu;
-    int N, C, K, Kpad, Mpad, Mrows, Mstride;
+    int N, C, K, Kpad, Mpad, Mrows;
 };
 
 template <int MG, bool INV>
 __global__ __launch_bounds__(256, 2) void dft_gemm_kernel(DgParams p) {
     constexpr int MGR = MG * 32;
-    __shared__ __attribute__((aligned(16))) float fbuf[2][KC * MGR];
+    // matrix chunk in LDS: [k][32 rows-in-tile][MGP tiles] - a lane's A values of all its row tiles for one k are
+    // contiguous, one ds_read_b128 per four tiles instead of a 4-byte read per MFMA (lane stride 16 or 48 bytes: the
+    // 16-byte reads of 8 consecutive lanes cover all 32 banks once)
+    constexpr int MGP = MG <= 4 ? 4 : 12;
+    constexpr int CHUNK = KC * 32 * MGP;
+    __shared__ __attribute__((aligned(16))) float fbuf[2][CHUNK];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, half = lane >> 5;
@@ -89,29 +94,18 @@ __global__ __launch_bounds__(256, 2) void dft_gemm_kernel(DgParams p) {
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
     const int nchunk = p.Kpad / KC;
-    // matrix chunk: KC rows of MGR floats (row stride Mpad) -> LDS [k][MGR]; float4 items, FPT per thread
-    constexpr int F4 = KC * MGR / 4;
-    constexpr int FPT = (F4 + 255) / 256;
+    // the table is laid out [group][k][32][MGP] (step_amd/dft.py), so a chunk is one contiguous run: a linear copy
+    constexpr int FPT = CHUNK / 4 / 256;
+    static_assert(CHUNK % 1024 == 0, "chunk copy");
     f32x4 freg[FPT];
-    unsigned foff[FPT];                                  // this thread's items inside a chunk (floats), computed once
-#pragma unroll
-    for (int i = 0; i < FPT; ++i) {
-        const int e = tid + i * 256;
-        const int kr = e / (MGR / 4), q = e - kr * (MGR / 4);
-        foff[i] = (unsigned)(kr * p.Mstride + m0 + q * 4);
-    }
+    const float* fsrc = p.matt + (size_t)g * p.Kpad * 32 * MGP + tid * 4;
     auto load_f = [&](int kc) {
-        const float* src = p.matt + (size_t)kc * KC * p.Mstride;
 #pragma unroll
-        for (int i = 0; i < FPT; ++i)
-            if (tid + i * 256 < F4) freg[i] = *reinterpret_cast<const f32x4*>(src + foff[i]);
+        for (int i = 0; i < FPT; ++i) freg[i] = *reinterpret_cast<const f32x4*>(fsrc + (size_t)kc * CHUNK + i * 1024);
     };
     auto store_f = [&](int b) {
 #pragma unroll
-        for (int i = 0; i < FPT; ++i) {
-            const int e = tid + i * 256;
-            if (e < F4) *reinterpret_cast<f32x4*>(&fbuf[b][e * 4]) = freg[i];
-        }
+        for (int i = 0; i < FPT; ++i) *reinterpret_cast<f32x4*>(&fbuf[b][tid * 4 + i * 1024]) = freg[i];
     };
     float bcur[KC / 2], bnxt[KC / 2];
     auto load_b = [&](int kc, float (&b)[KC / 2]) {
@@ -135,14 +129,15 @@ __global__ __launch_bounds__(256, 2) void dft_gemm_kernel(DgParams p) {
     for (int kc = 0; kc < nchunk; ++kc) {
         const bool more = kc + 1 < nchunk;
         if (more) { load_f(kc + 1); load_b(kc + 1, bnxt); }
-        const float* fb = fbuf[kc & 1] + half * MGR + l31;
+        const float* fb = fbuf[kc & 1] + (half * 32 + l31) * MGP;
 #pragma unroll
         for (int ks = 0; ks < KC / 2; ++ks) {
-            float a[MG];
+            f32x4 a[MGP / 4];
 #pragma unroll
-            for (int i = 0; i < MG; ++i) a[i] = fb[(2 * ks) * MGR + i * 32];
+            for (int q = 0; q < (MG + 3) / 4; ++q) a[q] = *reinterpret_cast<const f32x4*>(fb + (2 * ks) * 32 * MGP + q * 4);
 #pragma unroll
-            for (int i = 0; i < MG; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bcur[ks], acc[i], 0, 0, 0);
+            for (int i = 0; i < MG; ++i)
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i >> 2][i & 3], bcur[ks], acc[i], 0, 0, 0);
         }
         if (more) {
             store_f((kc + 1) & 1);
@@ -498,7 +493,6 @@ int launch_gemm(DgParams p, hipStream_t st, const char* what) {
     const int mtiles = p.Mpad / 32;
     const int mg = mtiles == 1 ? 2 : pick_mg(mtiles);
     const int groups = step::ceil_div(mtiles, mg);
-    p.Mstride = groups * mg * 32;
     const dim3 grid((unsigned)groups, (unsigned)(p.C / 8), (unsigned)p.N);
 #define DG_CASE(MGV) case MGV: hipLaunchKernelGGL((dft_gemm_kernel<MGV, INV>), grid, dim3(256), 0, st, p); break
     switch (mg) {
@@ -517,13 +511,16 @@ extern "C" int step_dft_rows(int T, int Kt) {
     return step::round_up(T + (Kt - 1) / 2 + 1, 32);
 }
 
-// row stride (floats) of the k-major matrix step_dft_fwd / step_dft_inv read for `rows` output rows: the rows padded to
-// whole groups of row tiles (columns past the real rows are zero)
-extern "C" int step_dft_table_stride(int rows) {
+// layout of the matrix step_dft_fwd / step_dft_inv read for `rows` output rows: [groups][Kpad][32][mgp] floats, element
+// (g, k, l, i) = M[row (g * mg + i) * 32 + l][k], zero where the row or k does not exist; returns mg, *mgp = its padded
+// extent (the kernels read 16 bytes at a time), *groups
+extern "C" int step_dft_table_geom(int rows, int* mgp, int* groups) {
     const int mtiles = step::ceil_div(rows, 32);
     if (mtiles < 1) return 0;
     const int mg = mtiles == 1 ? 2 : pick_mg(mtiles);
-    return step::ceil_div(mtiles, mg) * mg * 32;
+    if (mgp) *mgp = mg <= 4 ? 4 : 12;
+    if (groups) *groups = step::ceil_div(mtiles, mg);
+    return mg;
 }
 
 // groups of row tiles a launch of step_dft_fwd / step_dft_inv uses for `rows` output rows (statistics partial rows

@@ -34,6 +34,22 @@ def geometry(T, Kt):
     return rows, rows // 2, rows - 1            # rows = 2 NF, NF, L
 
 
+def _tile(m, rows_out, device):
+    """[K][rows_out] float64 (k-major) -> the kernels' layout [groups][Kpad][32][mgp] float32 on the device"""
+    import ctypes
+    mgp, groups = ctypes.c_int(0), ctypes.c_int(0)
+    mg = _lib.load().step_dft_table_geom(rows_out, ctypes.byref(mgp), ctypes.byref(groups))
+    mgp, groups = mgp.value, groups.value
+    K = m.shape[0]
+    kpad = (K + 15) // 16 * 16
+    full = torch.zeros(kpad, groups * mg * 32, dtype=torch.float64)
+    full[:K, :m.shape[1]] = m
+    t = full.view(kpad, groups, mg, 32).permute(1, 0, 3, 2)             # [groups][kpad][32][mg]
+    out = torch.zeros(groups, kpad, 32, mgp, dtype=torch.float64)
+    out[..., :mg] = t
+    return out.to(torch.float32).to(device).contiguous()
+
+
 def _angles(a, b, L):
     """2 pi (a b mod L) / L for integer grids a (column) and b (row), float64"""
     prod = torch.remainder(a.to(torch.int64)[:, None] * b.to(torch.int64)[None, :], L).to(torch.float64)
@@ -42,17 +58,12 @@ def _angles(a, b, L):
 
 def fwd_matrix(K, step, T, Kt, device):
     """k-major transform matrix for K samples taken at frames step * k of a length-T grid: [round_up(K,16)][stride],
-    column f < NF: cos(2 pi f step k / L), column NF + f: -sin(...)"""
+    column f < NF: cos(2 pi f step k / L), column NF + f: -sin(...); tiled by _tile"""
     key = ("fwd", K, step, T, Kt, str(device))
     if key not in _TABLES:
         rows, NF, L = geometry(T, Kt)
-        stride = _lib.query("step_dft_table_stride", rows)
-        kpad = (K + 15) // 16 * 16
         ang = _angles(torch.arange(K) * step, torch.arange(NF), L)          # [K][NF]
-        m = torch.zeros(kpad, stride, dtype=torch.float64)
-        m[:K, :NF] = torch.cos(ang)
-        m[:K, NF:2 * NF] = -torch.sin(ang)
-        _TABLES[key] = m.to(torch.float32).to(device).contiguous()
+        _TABLES[key] = _tile(torch.cat((torch.cos(ang), -torch.sin(ang)), dim=1), rows, device)
     return _TABLES[key]
 
 
@@ -62,14 +73,10 @@ def inv_matrix(T_out, step, T, Kt, device):
     key = ("inv", T_out, step, T, Kt, str(device))
     if key not in _TABLES:
         rows, NF, L = geometry(T, Kt)
-        stride = _lib.query("step_dft_table_stride", T_out)
         ang = _angles(torch.arange(NF), torch.arange(T_out) * step, L)      # [NF][T_out]
         kap = torch.full((NF, 1), 2.0 / L, dtype=torch.float64)
         kap[0, 0] = 1.0 / L
-        m = torch.zeros(rows, stride, dtype=torch.float64)
-        m[:NF, :T_out] = kap * torch.cos(ang)
-        m[NF:2 * NF, :T_out] = -kap * torch.sin(ang)
-        _TABLES[key] = m.to(torch.float32).to(device).contiguous()
+        _TABLES[key] = _tile(torch.cat((kap * torch.cos(ang), -kap * torch.sin(ang)), dim=0), T_out, device)
     return _TABLES[key]
 
 

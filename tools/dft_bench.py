@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--t", type=int, default=240)
     ap.add_argument("--kt", type=int, default=75)
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--no-direct", action="store_true")
     a = ap.parse_args()
     d = "cuda:0"
     n, c, s, t, kt = a.n, a.c, a.stride, a.t, a.kt
@@ -68,7 +69,7 @@ def main():
         print("  %-22s %8.3f ms  %7.1f TFLOP/s executed" % (name, ms, flops / ms / 1e9), flush=True)
     print("  forward %.2f ms, backward (dgrad + wgrad) %.2f ms; direct-conv FLOPs per pass %.2f T -> %.0f / %.0f TFLOP/s equivalent"
           % (tot["fwd"], tot["bwd"], fl / 1e12, fl / tot["fwd"] / 1e9, 2 * fl / tot["bwd"] / 1e9))
-    if kt == 75:
+    if kt == 75 and not a.no_direct:
         wp = ops.tcn_pack(w, c, c, kt, s, 0)
         wpd = ops.tcn_pack(w, c, c, kt, s, 2)
         f = timeit(lambda: ops.tcn_conv(y, sc, sh, True, wp, b, None, None, None, None, None, False, n, c, c, t, to, kt, s, 0), a.reps)
