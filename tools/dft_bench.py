@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--kt", type=int, default=75)
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--no-direct", action="store_true")
+    ap.add_argument("--only", default="", help="run only the stages whose name contains this")
     a = ap.parse_args()
     d = "cuda:0"
     n, c, s, t, kt = a.n, a.c, a.stride, a.t, a.kt
@@ -45,10 +46,11 @@ def main():
     rows, NF, L = dft.geometry(t, kt)
     wf, wb = dft.weight_spectrum(w, c, t, kt, False)
     sums = torch.zeros(2 * c + 1, dtype=torch.float64, device=d)
-    sa = dft.transform(y, sc, sh, True, 1, t, kt)
-    sm = dft.mix(sa, wf, c)
-    sdu = dft.transform(du, None, None, False, s, t, kt)
-    smb = dft.mix(sdu, wb, c)
+    want = lambda *names: not a.only or any(a.only in x for x in names)      # set up only what the chosen stages read
+    sa = dft.transform(y, sc, sh, True, 1, t, kt) if want("fwd: mix", "bwd: wgrad", "fwd: inverse(+stats)") or not a.only else None
+    sm = dft.mix(sa, wf, c) if want("fwd: inverse(+stats)") else None
+    sdu = dft.transform(du, None, None, False, s, t, kt) if want("bwd: mix", "bwd: inverse", "bwd: wgrad") else None
+    smb = dft.mix(sdu, wb, c) if want("bwd: inverse") else None
     fl = 2.0 * c * c * kt * to * 16 * n
     stages = [
         ("wspec", lambda: dft.weight_spectrum(w, c, t, kt, False), 0),
@@ -61,8 +63,10 @@ def main():
         ("bwd: wgrad", lambda: dft.conv_wgrad(sdu, sa, t, kt, False, tuple(w.shape)), 2.0 * 4 * c * c * 16 * NF * n),
     ]
     tot = {"fwd": 0.0, "bwd": 0.0}
-    print("C=%d s=%d T=%d N=%d Kt=%d: rows=%d L=%d, spectrum %.2f GB" % (c, s, t, n, kt, rows, L, sa.numel() * 4 / 1e9))
+    print("C=%d s=%d T=%d N=%d Kt=%d: rows=%d L=%d, spectrum %.2f GB" % (c, s, t, n, kt, rows, L, n * rows * c * 64 / 1e9))
     for name, fn, flops in stages:
+        if a.only and a.only not in name:
+            continue
         ms = timeit(fn, a.reps)
         if name[:3] in tot:
             tot[name[:3]] += ms

@@ -18,7 +18,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SOURCES = ["step_amd/csrc/tcn_wgrad_sw.hip", "step_amd/csrc/tcn_wgrad.hip", "step_amd/csrc/tcn.hip",
-           "step_amd/csrc/tcn_pack.h", "step_amd/csrc/common.h"]
+           "step_amd/csrc/tcn_pack.h", "step_amd/csrc/common.h", "step_amd/csrc/tcn_dft.hip"]
 LINE = re.compile(r"^(.*?)\s+([A-Z_]+)\s+n=(\d+) mean=([0-9.eE+-]+) mean_dur_ns=(\d+)\s*$")
 N, C, T, S, KT = 4096, 64, 240, 2, 75
 
@@ -75,7 +75,35 @@ def main(src="gpurun_out"):
             ent["hbm_bytes"] = float("%.4g" % ((2 * f + w) * 1024))
             # stride 2: forward = <5, 38, 2, ...>, input gradient = two output phases of 19 taps <5, 19, 1, ...>
             res["tcn_fwd_b1" if "38, 2" in k else "tcn_dgrad_b1"] = ent
+    # frequency-domain stage kernels (tools/gpu_pmc_dft.sh: one stage per run, so the per-kernel means are per launch).
+    # NOTE the helper launches of a run (transform of a / dout that feed the stage) share the kernel template; the
+    # stage itself is the LAST launch and the only one repeated, the means below are over all launches of that name in
+    # the run and are therefore used only for the stage whose launches all have one shape.
+    rows = (T + 38 + 31) // 32 * 32
+    spec = 4 * N * rows * C * 16
+    for key, st, templ, alg_d in (("dft_transform_b1", "tr", "dft_gemm_kernel<9, false>", 4 * N * C * T * 16 + spec),
+                                  ("dft_inverse_bwd_b1", "ib", "dft_gemm_kernel<4, true>", spec + 4 * N * C * T * 16)):
+        try:
+            mfd, fed, wrd = (read(os.path.join(ROOT, src, "pmc_dft_%s_%s.txt" % (st, k))) for k in ("mfma", "fetch", "write"))
+        except OSError:
+            continue
+        if templ not in fed or templ not in wrd or templ not in mfd:
+            continue
+        f, dur_f = fed[templ]["FETCH_SIZE"]
+        w, dur_w = wrd[templ]["WRITE_SIZE"]
+        gui, dur_m = mfd[templ]["GRBM_GUI_ACTIVE"]
+        busy = mfd[templ]["SQ_VALU_MFMA_BUSY_CYCLES"][0]
+        res[key] = {"kernel": templ, "ms": round((dur_f + dur_w) / 2e6, 3), "FETCH_SIZE_KB": round(f, 1),
+                    "WRITE_SIZE_KB": round(w, 1), "mfma_busy": round(busy / 1024 / (gui / 8), 4),
+                    "clock_ghz": round(gui / 8 / dur_m, 3), "algorithmic_bytes": alg_d,
+                    "hbm_bytes": float("%.4g" % ((2 * f + w) * 1024)),
+                    "command": "python3 tools/dft_bench.py --reps 1 --no-direct --only ... (tools/gpu_pmc_dft.sh)"}
     json.dump(res, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
+    for k in ("dft_transform_b1", "dft_inverse_bwd_b1"):
+        if k in res:
+            e = res[k]
+            print("%-18s %-30s %7.3f ms  hbm %.3g B (algorithmic %.3g)  mfma busy %.3f @ %.2f GHz" %
+                  (k, e["kernel"], e["ms"], e["hbm_bytes"], e["algorithmic_bytes"], e["mfma_busy"], e["clock_ghz"]))
     for k in ("tcn_wgrad_b1", "tcn_fwd_b1", "tcn_dgrad_b1"):
         if k in res:
             e = res[k]
