@@ -398,28 +398,30 @@ __global__ __launch_bounds__(256) void dft_cfold_kernel(const float* __restrict_
     chat[(size_t)(2 * f + 1) * Co * Ci + co * Ci + ci] = cim * kap;
 }
 
+constexpr int TAPS_PER_THREAD = 8;           // blockIdx.y = group of 8 taps: ~10x the threads of one-thread-per-(co, ci)
 __global__ __launch_bounds__(64) void dft_taps_kernel(const float* __restrict__ chat, const float* __restrict__ tc,
                                                       const float* __restrict__ ts, float* __restrict__ dw, int Ci, int Co,
                                                       int NF, int Kt, int transposed) {
     const int e = blockIdx.x * 64 + threadIdx.x;
     if (e >= Co * Ci) return;
     const int co = e / Ci, ci = e - co * Ci;
-    float acc[80];
+    const int j0 = blockIdx.y * TAPS_PER_THREAD;
+    float acc[TAPS_PER_THREAD];
 #pragma unroll
-    for (int j = 0; j < 80; ++j) acc[j] = 0.f;
+    for (int j = 0; j < TAPS_PER_THREAD; ++j) acc[j] = 0.f;
     for (int f = 0; f < NF; ++f) {
         const float cr = chat[(size_t)(2 * f) * Co * Ci + e], cim = chat[(size_t)(2 * f + 1) * Co * Ci + e];
-        const float* c = tc + (size_t)f * Kt;
-        const float* s = ts + (size_t)f * Kt;
+        const float* c = tc + (size_t)f * Kt + j0;
+        const float* s = ts + (size_t)f * Kt + j0;
 #pragma unroll
-        for (int j = 0; j < 80; ++j)
-            if (j < Kt) acc[j] += cr * c[j] - cim * s[j];
+        for (int j = 0; j < TAPS_PER_THREAD; ++j)
+            if (j0 + j < Kt) acc[j] += cr * c[j] - cim * s[j];
     }
 #pragma unroll
-    for (int j = 0; j < 80; ++j)
-        if (j < Kt) {
-            if (!transposed) dw[((size_t)co * Ci + ci) * Kt + j] = acc[j];
-            else dw[((size_t)ci * Co + co) * Kt + (Kt - 1 - j)] = acc[j];
+    for (int j = 0; j < TAPS_PER_THREAD; ++j)
+        if (j0 + j < Kt) {
+            if (!transposed) dw[((size_t)co * Ci + ci) * Kt + j0 + j] = acc[j];
+            else dw[((size_t)ci * Co + co) * Kt + (Kt - 1 - j0 - j)] = acc[j];
         }
 }
 
@@ -620,7 +622,7 @@ extern "C" int step_dft_wgrad(const float* dspec, const float* spec, const float
                               float* db, int N, int Ci, int Co, int NF, int Kt, int transposed, void* ws,
                               size_t ws_bytes, void* stream) {
     STEP_REQUIRE(dspec && spec && tc && ts && dw && ws, "step_dft_wgrad: null pointer");
-    STEP_REQUIRE(N >= 1 && (Ci == 32 || Ci == 64) && Co == Ci && NF >= 1 && Kt >= 1 && Kt <= 80,
+    STEP_REQUIRE(N >= 1 && (Ci == 32 || Ci == 64) && Co == Ci && NF >= 1 && Kt >= 1,
                  "step_dft_wgrad: unsupported N=%d Ci=%d Co=%d NF=%d Kt=%d", N, Ci, Co, NF, Kt);
     if (ws_bytes < step_dft_wgrad_ws_bytes(N, Ci, Co, NF)) {
         step::set_error("step_dft_wgrad: workspace %zu < %zu bytes", ws_bytes, step_dft_wgrad_ws_bytes(N, Ci, Co, NF));
@@ -638,7 +640,7 @@ extern "C" int step_dft_wgrad(const float* dspec, const float* spec, const float
                        Ci, Co, NF, p.nsplit, 2 * NF - 1);
     rc = step::check_launch("step_dft_wgrad(fold)");
     if (rc != STEP_OK) return rc;
-    hipLaunchKernelGGL(dft_taps_kernel, dim3(step::ceil_div(Co * Ci, 64)), dim3(64), 0, st, (const float*)chat, tc, ts, dw,
+    hipLaunchKernelGGL(dft_taps_kernel, dim3(step::ceil_div(Co * Ci, 64), step::ceil_div(Kt, TAPS_PER_THREAD)), dim3(64), 0, st, (const float*)chat, tc, ts, dw,
                        Ci, Co, NF, Kt, transposed);
     rc = step::check_launch("step_dft_wgrad(taps)");
     if (rc != STEP_OK || !db) return rc;
