@@ -123,7 +123,7 @@ def time_dft_kernels(n, t, device, reps=3):
         w = (torch.randn(c, c, 75, 1, generator=g) * 0.02).to(device)
         b = torch.zeros(c, device=device)
         sc, sh = torch.ones(c, device=device), torch.zeros(c, device=device)
-        wf, wb = dft.weight_spectrum(w, c, tin, 75, False)
+        wf, wb = dft.weight_spectrum(w, c, tin, 75, False, tout, s)
         sums = torch.zeros(2 * c + 1, dtype=torch.float64, device=device)
         sa = dft.transform(y, sc, sh, True, 1, tin, 75)
         sm = dft.mix(sa, wf, c)
@@ -138,7 +138,7 @@ def time_dft_kernels(n, t, device, reps=3):
             ("dft_transform_dout", lambda: dft.transform(du, None, None, False, s, tin, 75), 2.0 * rows * tout * c * 16 * n, 4.0 * du.numel() + spec_bytes),
             ("dft_mix_bwd", lambda: dft.mix(sdu, wb, c), fmix, 2 * spec_bytes),
             ("dft_inverse_bwd", lambda: dft.inverse(smb, None, tin, 1, tin, 75), 2.0 * rows * tin * c * 16 * n, spec_bytes + 4.0 * y.numel()),
-            ("dft_wgrad", lambda: dft.conv_wgrad(sdu, sa, tin, 75, False, tuple(w.shape)), fmix, 2 * spec_bytes),
+            ("dft_wgrad", lambda: dft.conv_wgrad(sdu, sa, tin, 75, False, tuple(w.shape), tout, s), fmix, 2 * spec_bytes),
         ]
         for name, fn, fl, nbytes in stages:
             fn()

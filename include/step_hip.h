@@ -352,17 +352,25 @@ int step_tcn_wgrad_split(const float* dout, const float* in,
  * ConvTranspose2d twin CVAE_stgcn.py:359-365) computed as  transform -> per-bin channel mixing -> inverse transform,
  * every stage an fp32 GEMM on the matrix cores (csrc/tcn_dft.hip has the algebra).  Spectrum layout:
  * S[n][f2][c][v] fp32, f2 in [0, rows), rows = 2 NF = step_dft_rows(T, Kt), f2 < NF real parts, else imaginary;
- * L = rows - 1.  The cos / sin matrices are the caller's (step_amd/dft.py builds them in float64), tiled for the kernels:
- * matt[group][k][32][mgp] with (mg, mgp, groups) = step_dft_table_geom(output rows), zero past the real extents.  C % 8 == 0.
- *   step_dft_fwd   S = F . act(in)      in (N,C,K,16) [BN scale/shift + ReLU on the load], k padded to a multiple of 16
+ * L = rows - 1.  Both transforms are HALF the dense DFT's size: the frames are paired about their centre (hi = Kh + j,
+ * lo = Kh - 1 - j, Kh = ceil(K / 2)), the cos rows act on the pair sums, the sin rows on the pair differences, and a
+ * spectrum's time origin is that centre, step * (Kh - 1/2); the inverse produces E[j] and O[j] and writes E + O, E - O.
+ * The origin shift between a conv's input and output (0 at stride 1, half a frame at stride 2) is a phase in the tap
+ * tables tc / ts = cos / sin(2 pi f (j - P + delta) / L) that step_dft_wspec and step_dft_wgrad read.
+ * The cos / sin matrices are the caller's (step_amd/dft.py builds them in float64), tiled for the kernels:
+ * [group][k][32][mgp] with (mg, mgp, groups) = step_dft_table_geom(rows of the matrix, inverse), zero past the real
+ * extents; the forward table is the cos half's tiling (NF rows, k < Kh) followed by the sin half's, the inverse table has
+ * ceil(T_out / 2) rows and k < 2 NF (cos part against the real rows, sin part against the imaginary rows).  C % 8 == 0.
+ *   step_dft_fwd   S = F . act(in)      in (N,C,K,16) [BN scale/shift + ReLU on the load]
  *   step_dft_mix   out[n][.][co][v] = W[f] . in[n][.][ci][v] per bin; wmat [NF][2 Ci][2 Co] from step_dft_wspec
  *   step_dft_inv   out (N,C,T_out,16) = G . S (+ bias); optional SUM out, SUM out^2 per channel (as step_tcn_conv_stats),
  *                  or step_tcn_conv's eval-mode epilogue (BN2 affine, residual with its affine, ReLU: classifier.py:189-191)
  *   step_dft_wspec taps (Co,Ci,Kt) [or the ConvTranspose2d layout] -> forward and backward mixing matrices
- *   step_dft_wgrad dw, db from the spectra of dout and of the activated input (kept from the forward pass)         */
+ *   step_dft_wgrad dw, db from the spectra of dout and of the activated input (kept from the forward pass)
+ *   step_dft_groups(T_out): partial-sum rows per sample that step_dft_inv's statistics use (step_dft_inv_ws_bytes)  */
 int step_dft_rows(int T, int Kt);
-int step_dft_table_geom(int rows, int* mgp, int* groups);
-int step_dft_groups(int rows);
+int step_dft_table_geom(int rows, int inverse, int* mgp, int* groups);
+int step_dft_groups(int T_out);
 int step_dft_fwd(const float* in, const float* in_scale, const float* in_shift, int in_relu,
                  const float* matt, float* spec, int N, int C, int K, int rows, void* stream);
 int step_dft_mix(const float* in, const float* wmat, float* out, int N, int Ci, int Co, int NF, void* stream);

@@ -49,7 +49,7 @@ SIGNATURES = {
     "step_tcn_conv_stats_ws_bytes": (Z, [I, I, I]),
     "step_tcn_conv_stats": (I, [P, P, P, I, P, P, P, I, I, I, I, I, I, I, I, P, P, Z, P]),
     "step_dft_rows": (I, [I, I]),
-    "step_dft_table_geom": (I, [I, P, P]),
+    "step_dft_table_geom": (I, [I, I, P, P]),
     "step_dft_groups": (I, [I]),
     "step_dft_fwd": (I, [P, P, P, I, P, P, I, I, I, I, P]),
     "step_dft_mix": (I, [P, P, P, I, I, I, I, P]),

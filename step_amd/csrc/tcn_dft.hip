@@ -31,13 +31,20 @@ static __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_n(const float* bas
 static __device__ __forceinline__ int rowmap(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
 // ------------------------------------------------------------------------------------------------------------
-// Left-multiplication of every sample's [K x (C * 16)] matrix by a fixed [Mpad x K] matrix (stored k-major:
-// matt[k][Mpad], rows past the real extent and k past K are zero).
-//   INV == 0 (to the frequency domain): In(n,k,c,v) = act(in[n][c][k][v]),  Out = S[n][m][c][v]
-//   INV == 1 (back):                    In(n,k,c,v) = S[n][k][c][v],        Out = out[n][c][m][v] (+ bias, statistics)
+// Left-multiplication of every sample's [K x (C * 16)] matrix by a fixed matrix, HALF the dense transform's size in
+// each direction: the frames are paired about their centre (hi = Kh + j, lo = Kh - 1 - j, Kh = ceil(K / 2); the
+// spectrum's time origin is that centre, s (Kh - 1/2), which costs nothing: the difference between the origins of a
+// conv's input and output is a phase folded into the weight spectrum and the tap tables, step_amd/dft.py), so that
+//   Re X[f] = SUM_j (x[hi] + x[lo]) cos(th_fj),   Im X[f] = - SUM_j (x[hi] - x[lo]) sin(th_fj),   th_fj = 2 pi f s (j + 1/2) / L
+//   x[hi], x[lo] = E[j] +- O[j],   E[j] = SUM_f kap_f / L cos(th_fj) Re X[f],   O[j] = - SUM_f kap_f / L sin(th_fj) Im X[f]
+//   INV == 0 (to the frequency domain): row-tile groups [0, gh) are the cos rows on the pair sums, [gh, 2 gh) the sin
+//            rows on the pair differences; In(n,k,c,v) = act(in[n][c][k][v]),  Out = S[n][m][c][v]
+//   INV == 1 (back): rows = pairs j; the first NF k (Re rows of S) accumulate E, the last NF (Im rows) O; the epilogue
+//            writes frames hi and lo: Out = out[n][c][frame][v] (+ bias, statistics, eval-mode tail)
+// The matrix is stored k-major and tiled (step_dft_table_geom); rows past the real extent and k past K are zero.
 // Block = 4 waves = (sample, 8 channels = 4 column tiles of 2 channels x 16 joints, group of MG row tiles); wave w owns
 // column tile w and all MG row tiles.  The matrix streams through LDS in chunks of KC = 16 k (double-buffered, one
-// barrier per chunk); the B operand is the lane's own 4-byte load (64 contiguous bytes per 16 lanes), a chunk ahead.
+// barrier per chunk); the B operand is the lane's own 4-byte loads (64 contiguous bytes per 16 lanes), a chunk ahead.
 constexpr int KC = 16;
 
 struct DgParams {
@@ -55,12 +62,14 @@ struct DgParams {
     float* out;
     double* stat_part;       // INV == 1: [N * groups][C][2] partial SUM out, SUM out^2, or null
     int in_relu;
-    int N, C, K, Kpad, Mpad, Mrows;
+    int N, C, K, Kpad, Mpad, Mrows;   // INV == 0: K frames, Kpad = round_up(ceil(K/2), KC), Mrows = 2 NF; INV == 1: K = Kpad = 2 NF, Mrows = T_out
+    int gh;                           // INV == 0: row-tile groups per half (cos | sin)
 };
 
 template <int MG, bool INV>
 __global__ __launch_bounds__(256, 2) void dft_gemm_kernel(DgParams p) {
     constexpr int MGR = MG * 32;
+    constexpr int NACC = INV ? 2 * MG : MG;            // INV: E tiles, then O tiles
     // matrix chunk in LDS: [k][32 rows-in-tile][MGP tiles] - a lane's A values of all its row tiles for one k are
     // contiguous, one ds_read_b128 per four tiles instead of a 4-byte read per MFMA (lane stride 16 or 48 bytes: the
     // 16-byte reads of 8 consecutive lanes cover all 32 banks once)
@@ -71,25 +80,30 @@ __global__ __launch_bounds__(256, 2) void dft_gemm_kernel(DgParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, half = lane >> 5;
     const int cpar = l31 >> 4, v = l31 & 15;
-    const int groups = gridDim.x;                       // row-tile groups (fastest: they share the B operand in L2)
-    const int g = blockIdx.x;
+    const int g = blockIdx.x;                           // row-tile group (fastest: groups share the B operand in L2)
     const int cg = blockIdx.y, n = blockIdx.z;
     const int c = cg * 8 + wave * 2 + cpar;
-    const int m0 = g * MGR;
+    const int odd = !INV && g >= p.gh;                  // INV == 0: this group holds sin rows (on the pair differences)
+    const int m0 = (INV ? g : g - odd * p.gh) * MGR;    // first row of the group within its half / first pair
 
-    // B operand addressing: descriptor on the sample, one lane offset, uniform k offsets
+    // B operand addressing: descriptor on the sample, lane offsets, uniform k offsets
     const size_t sample = (size_t)p.C * p.K * 16;
     const __amdgpu_buffer_rsrc_t rs = rsrc_n(p.in + (size_t)n * sample, (unsigned)(sample * 4));
+    const int Kh = (p.K + 1) >> 1;                      // INV == 0: pairs of frames
     const unsigned kstride = INV ? (unsigned)p.C * 64u : 64u;                       // bytes per k
-    const unsigned voff = (INV ? (unsigned)c * 64u : (unsigned)c * (unsigned)p.K * 64u) + half * kstride + v * 4u;
+    const unsigned voff = INV ? (unsigned)c * 64u + half * kstride + v * 4u
+                              : ((unsigned)c * (unsigned)p.K + (unsigned)(Kh + half)) * 64u + v * 4u;      // frame hi of pair `half`
+    const unsigned voff_lo = ((unsigned)c * (unsigned)p.K + (unsigned)(Kh - 1 - half)) * 64u + v * 4u;      // frame lo
     float sc = 1.f, sh = 0.f;
     const bool act = !INV && p.in_scale != nullptr;
     if (act) { sc = p.in_scale[c]; sh = p.in_shift[c]; }
     const float lo = (!INV && p.in_relu) ? 0.f : -__builtin_inff();
+    const float sg = odd ? -1.f : 1.f;
+    const int nhi = p.K - Kh;                           // pairs whose hi frame exists (K odd: one fewer than Kh)
 
-    f32x16 acc[MG];
+    f32x16 acc[NACC];
 #pragma unroll
-    for (int i = 0; i < MG; ++i)
+    for (int i = 0; i < NACC; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
@@ -111,22 +125,21 @@ __global__ __launch_bounds__(256, 2) void dft_gemm_kernel(DgParams p) {
     auto load_b = [&](int kc, float (&b)[KC / 2]) {
 #pragma unroll
         for (int ks = 0; ks < KC / 2; ++ks) {
-            const int k = kc * KC + 2 * ks;                                  // (+ half: in the lane offset)
-            float x = bload(rs, voff, (unsigned)k * kstride);
-            if constexpr (!INV) {
-                if (act) x = x * sc + sh;
-                x = fmaxf(x, lo);
-                x = (k + half < p.K) ? x : 0.f;                               // k padding (the matrix rows there are 0 too)
+            const int k = kc * KC + 2 * ks;                                  // (+ half: in the lane offsets)
+            if constexpr (INV) {
+                b[ks] = bload(rs, voff, (unsigned)k * kstride);
+            } else {
+                float xh = bload(rs, voff + (unsigned)k * 64u, 0u);     // (offsets in the VGPR: the range check sees all of them)
+                float xl = bload(rs, voff_lo - (unsigned)k * 64u, 0u);
+                if (act) { xh = xh * sc + sh; xl = xl * sc + sh; }
+                xh = fmaxf(xh, lo); xl = fmaxf(xl, lo);
+                xh = (k + half < nhi) ? xh : 0.f;                             // the odd frame out / k padding (the matrix is 0 there too)
+                xl = (k + half < Kh) ? xl : 0.f;
+                b[ks] = xh + sg * xl;
             }
-            b[ks] = x;
         }
     };
-
-    load_f(0);
-    load_b(0, bcur);
-    store_f(0);
-    __syncthreads();
-    for (int kc = 0; kc < nchunk; ++kc) {
+    auto chunk = [&](int kc, f32x16* A) {
         const bool more = kc + 1 < nchunk;
         if (more) { load_f(kc + 1); load_b(kc + 1, bnxt); }
         const float* fb = fbuf[kc & 1] + (half * 32 + l31) * MGP;
@@ -137,7 +150,7 @@ __global__ __launch_bounds__(256, 2) void dft_gemm_kernel(DgParams p) {
             for (int q = 0; q < (MG + 3) / 4; ++q) a[q] = *reinterpret_cast<const f32x4*>(fb + (2 * ks) * 32 * MGP + q * 4);
 #pragma unroll
             for (int i = 0; i < MG; ++i)
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i >> 2][i & 3], bcur[ks], acc[i], 0, 0, 0);
+                A[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i >> 2][i & 3], bcur[ks], A[i], 0, 0, 0);
         }
         if (more) {
             store_f((kc + 1) & 1);
@@ -145,49 +158,68 @@ __global__ __launch_bounds__(256, 2) void dft_gemm_kernel(DgParams p) {
             for (int ks = 0; ks < KC / 2; ++ks) bcur[ks] = bnxt[ks];
         }
         __syncthreads();
+    };
+
+    load_f(0);
+    load_b(0, bcur);
+    store_f(0);
+    __syncthreads();
+    if constexpr (!INV) {
+        for (int kc = 0; kc < nchunk; ++kc) chunk(kc, acc);
+    } else {
+        const int nre = nchunk >> 1;                                          // K = 2 NF, NF a multiple of KC
+        for (int kc = 0; kc < nre; ++kc) chunk(kc, acc);
+        for (int kc = nre; kc < nchunk; ++kc) chunk(kc, acc + MG);
     }
 
     if constexpr (!INV) {
-        // S[n][m][c][v]: 32 lanes (2 channels x 16 joints) write 128 contiguous bytes per row
-        // (descriptor on the sample's spectrum: rows past the end - a last, partial group - fall outside and are dropped)
+        // S[n][m][c][v]: 32 lanes (2 channels x 16 joints) write 128 contiguous bytes per row; the descriptor ends with
+        // this half's rows (NF is not a multiple of 32: the padding rows of the cos half must not land in the sin half)
+        const int NF = p.Mrows >> 1;
         const size_t osample = (size_t)p.Mrows * p.C * 16;
-        const __amdgpu_buffer_rsrc_t ro = rsrc_n(p.out + (size_t)n * osample, (unsigned)(osample * 4));
+        const __amdgpu_buffer_rsrc_t ro = rsrc_n(p.out + (size_t)n * osample, (unsigned)((size_t)(odd + 1) * NF * p.C * 64));
         const unsigned rowb = (unsigned)p.C * 64u;
-        const unsigned ol = ((unsigned)(m0 + 4 * half) * (unsigned)p.C * 16u + (unsigned)c * 16u + v) * 4u;
+        const unsigned ol = ((unsigned)(odd * NF + m0 + 4 * half) * (unsigned)p.C * 16u + (unsigned)c * 16u + v) * 4u;
 #pragma unroll
         for (int i = 0; i < MG; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                bstore(ro, ol, (unsigned)(i * 32 + (r & 3) + 8 * (r >> 2)) * rowb, acc[i][r]);
+                bstore(ro, ol + (unsigned)(i * 32 + (r & 3) + 8 * (r >> 2)) * rowb, 0u, acc[i][r]);
     } else {
         const float bia = p.bias ? p.bias[c] : 0.f;
         float osc = 1.f, osh = 0.f, rsc = 1.f, rsh = 0.f;
         if (p.out_scale) { osc = p.out_scale[c]; osh = p.out_shift[c]; }
         if (p.res && p.res_scale) { rsc = p.res_scale[c]; rsh = p.res_shift[c]; }
         const bool epi = p.out_scale != nullptr || p.res != nullptr || p.out_relu != 0;       // (uniform)
-        // descriptor on the sample; the lane's channel row starts at c * Mrows frames, frames past Mrows (padding rows
-        // of the last tile) must not spill into the next channel: they are masked
+        // descriptor on the sample; pair j -> frames Th + j and Th - 1 - j of the lane's channel row, both masked
+        // (padding pairs of the last tile, the odd frame out)
+        const int Th = (p.Mrows + 1) >> 1;
         const size_t osample = (size_t)p.C * p.Mrows * 16;
         const __amdgpu_buffer_rsrc_t ro = rsrc_n(p.out + (size_t)n * osample, (unsigned)(osample * 4));
         const __amdgpu_buffer_rsrc_t rr = rsrc_n(p.res ? p.res + (size_t)n * osample : p.out, p.res ? (unsigned)(osample * 4) : 0u);
-        const unsigned ol = ((unsigned)c * (unsigned)p.Mrows * 16u + (unsigned)(m0 + 4 * half) * 16u + v) * 4u;
-        const int mlim = p.Mrows - m0 - 4 * half;          // rows (relative to this lane's first) that exist
+        const int j0 = m0 + 4 * half;
+        const unsigned ol_hi = ((unsigned)c * (unsigned)p.Mrows * 16u + (unsigned)(Th + j0) * 16u + v) * 4u;
+        const unsigned ol_lo = ((unsigned)c * (unsigned)p.Mrows * 16u + (unsigned)(Th - 1 - j0) * 16u + v) * 4u;
+        const int nlo = Th - j0, nhi_o = p.Mrows - Th - j0;          // pairs (relative to the lane's first) whose lo / hi frame exists
         float s1 = 0.f, s2 = 0.f;
+        auto finish = [&](float x, unsigned off) {
+            x += bia;
+            if (epi) {
+                x = x * osc + osh;
+                if (p.res) x += bload(rr, off, 0u) * rsc + rsh;
+                if (p.out_relu) x = fmaxf(x, 0.f);
+            }
+            bstore(ro, off, 0u, x);
+            s1 += x; s2 += x * x;
+        };
 #pragma unroll
         for (int i = 0; i < MG; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int mr = i * 32 + (r & 3) + 8 * (r >> 2);
-                if (mr < mlim) {
-                    float x = acc[i][r] + bia;
-                    if (epi) {
-                        x = x * osc + osh;
-                        if (p.res) x += bload(rr, ol, (unsigned)mr * 64u) * rsc + rsh;
-                        if (p.out_relu) x = fmaxf(x, 0.f);
-                    }
-                    bstore(ro, ol, (unsigned)mr * 64u, x);
-                    s1 += x; s2 += x * x;
-                }
+                const float e = acc[i][r], o = acc[MG + i][r];
+                if (mr < nhi_o) finish(e + o, ol_hi + (unsigned)mr * 64u);
+                if (mr < nlo) finish(e - o, ol_lo - (unsigned)mr * 64u);
             }
         if (p.stat_part) {
             // per (block, channel): the 16 joints by DPP row rotations, the two halves by a shuffle; fp64 from here on
@@ -202,7 +234,7 @@ __global__ __launch_bounds__(256, 2) void dft_gemm_kernel(DgParams p) {
             a1 += __shfl_xor(a1, 32, 64);
             a2 += __shfl_xor(a2, 32, 64);
             if (half == 0 && v == 0) {
-                double* d = p.stat_part + (((size_t)n * groups + g) * p.C + c) * 2;
+                double* d = p.stat_part + (((size_t)n * gridDim.x + g) * p.C + c) * 2;
                 d[0] = (double)a1; d[1] = (double)a2;
             }
         }
@@ -476,33 +508,40 @@ __global__ __launch_bounds__(256) void dft_wspec_kernel(const float* __restrict_
     B[(size_t)(Co + co) * Mb + Ci + ci] = wr;
 }
 
-int pick_mg(int mtiles) {
-    // largest group that divides the tile count, else the one with the least padding
-    if (mtiles == 8) return 4;          // (8 tiles as one group is 272 registers: one wave per SIMD, measured slower)
-    const int cand[] = {9, 8, 5, 4, 3, 2};
-    for (int c : cand)
-        if (mtiles % c == 0) return c;
-    int best = 5, waste = 1 << 30;
-    for (int c : cand) {
-        const int w = step::ceil_div(mtiles, c) * c - mtiles;
-        if (w < waste) { waste = w; best = c; }
+int pick_mg(int mtiles, bool inverse) {
+    // largest group that divides the tile count, else the one with the least padding; the inverse keeps two
+    // accumulator sets (E and O), so its groups stop at 4 tiles (128 accumulator registers)
+    if (mtiles <= 1) return 2;
+    const int cand_f[] = {9, 8, 5, 4, 3, 2}, cand_i[] = {4, 3, 2};
+    const int* cand = inverse ? cand_i : cand_f;
+    const int nc = inverse ? 3 : 6;
+    for (int i = 0; i < nc; ++i)
+        if (mtiles % cand[i] == 0) return cand[i];
+    int best = cand[nc - 1], waste = 1 << 30;
+    for (int i = 0; i < nc; ++i) {
+        const int w = step::ceil_div(mtiles, cand[i]) * cand[i] - mtiles;
+        if (w < waste) { waste = w; best = cand[i]; }
     }
     return best;
 }
 
 template <bool INV>
 int launch_gemm(DgParams p, hipStream_t st, const char* what) {
+    // INV == 0: Mpad = round_up(NF, 32) rows per half, two halves; INV == 1: Mpad = round_up(ceil(T_out / 2), 32) pairs
     const int mtiles = p.Mpad / 32;
-    const int mg = mtiles == 1 ? 2 : pick_mg(mtiles);
+    const int mg = pick_mg(mtiles, INV);
     const int groups = step::ceil_div(mtiles, mg);
-    const dim3 grid((unsigned)groups, (unsigned)(p.C / 8), (unsigned)p.N);
-#define DG_CASE(MGV) case MGV: hipLaunchKernelGGL((dft_gemm_kernel<MGV, INV>), grid, dim3(256), 0, st, p); break
-    switch (mg) {
-        DG_CASE(2); DG_CASE(3); DG_CASE(4); DG_CASE(5); DG_CASE(8); DG_CASE(9);
-        default: step::set_error("%s: no kernel for %d row tiles", what, mtiles); return STEP_ERR_ARG;
+    p.gh = groups;
+    const dim3 grid((unsigned)(INV ? groups : 2 * groups), (unsigned)(p.C / 8), (unsigned)p.N);
+#define DG_CASE(MGV) case MGV: hipLaunchKernelGGL((dft_gemm_kernel<MGV, INV>), grid, dim3(256), 0, st, p); return step::check_launch(what)
+    if constexpr (INV) {
+        switch (mg) { DG_CASE(2); DG_CASE(3); DG_CASE(4); default: break; }
+    } else {
+        switch (mg) { DG_CASE(2); DG_CASE(3); DG_CASE(4); DG_CASE(5); DG_CASE(8); DG_CASE(9); default: break; }
     }
 #undef DG_CASE
-    return step::check_launch(what);
+    step::set_error("%s: no kernel for %d row tiles", what, mtiles);
+    return STEP_ERR_ARG;
 }
 
 }  // namespace
@@ -513,25 +552,25 @@ extern "C" int step_dft_rows(int T, int Kt) {
     return step::round_up(T + (Kt - 1) / 2 + 1, 32);
 }
 
-// layout of the matrix step_dft_fwd / step_dft_inv read for `rows` output rows: [groups][Kpad][32][mgp] floats, element
-// (g, k, l, i) = M[row (g * mg + i) * 32 + l][k], zero where the row or k does not exist; returns mg, *mgp = its padded
-// extent (the kernels read 16 bytes at a time), *groups
-extern "C" int step_dft_table_geom(int rows, int* mgp, int* groups) {
+// layout of the matrices step_dft_fwd / step_dft_inv read.  `rows` = the matrix's output rows: NF for each half (cos,
+// sin) of the forward matrix, ceil(T_out / 2) pairs for the inverse.  A matrix of `rows` rows is tiled
+// [groups][Kpad][32][mgp] floats, element (g, k, l, i) = M[row (g * mg + i) * 32 + l][k], zero where the row or k does not
+// exist (Kpad = round_up(ceil(K / 2), 16) forward, 2 NF inverse); the forward table is the cos half's tiling followed by
+// the sin half's.  Returns mg, *mgp = its padded extent (the kernels read 16 bytes at a time), *groups
+extern "C" int step_dft_table_geom(int rows, int inverse, int* mgp, int* groups) {
     const int mtiles = step::ceil_div(rows, 32);
     if (mtiles < 1) return 0;
-    const int mg = mtiles == 1 ? 2 : pick_mg(mtiles);
+    const int mg = pick_mg(mtiles, inverse != 0);
     if (mgp) *mgp = mg <= 4 ? 4 : 12;
     if (groups) *groups = step::ceil_div(mtiles, mg);
     return mg;
 }
 
-// groups of row tiles a launch of step_dft_fwd / step_dft_inv uses for `rows` output rows (statistics partial rows
-// per sample)
-extern "C" int step_dft_groups(int rows) {
-    const int mtiles = step::ceil_div(rows, 32);
+// row-tile groups a launch of step_dft_inv uses for T_out output frames (statistics partial rows per sample)
+extern "C" int step_dft_groups(int T_out) {
+    const int mtiles = step::ceil_div((T_out + 1) / 2, 32);
     if (mtiles < 1) return 0;
-    const int mg = mtiles == 1 ? 2 : pick_mg(mtiles);
-    return step::ceil_div(mtiles, mg);
+    return step::ceil_div(mtiles, pick_mg(mtiles, true));
 }
 
 extern "C" int step_dft_fwd(const float* in, const float* in_scale, const float* in_shift, int in_relu,
@@ -540,9 +579,10 @@ extern "C" int step_dft_fwd(const float* in, const float* in_scale, const float*
     STEP_REQUIRE(N >= 1 && N <= 65535 && C >= 8 && C % 8 == 0 && C / 8 <= 65535 && K >= 1 && rows >= 32 && rows % 32 == 0,
                  "step_dft_fwd: bad shape N=%d C=%d K=%d rows=%d", N, C, K, rows);
     STEP_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "step_dft_fwd: scale/shift pair");
+    STEP_REQUIRE((size_t)C * K * 64 < (1ull << 31) && (size_t)rows * C * 64 < (1ull << 31), "step_dft_fwd: sample too large");
     DgParams p{};
     p.in = in; p.matt = matt; p.in_scale = in_scale; p.in_shift = in_shift; p.in_relu = in_relu; p.out = spec;
-    p.N = N; p.C = C; p.K = K; p.Kpad = step::round_up(K, KC); p.Mpad = rows; p.Mrows = rows;
+    p.N = N; p.C = C; p.K = K; p.Kpad = step::round_up((K + 1) / 2, KC); p.Mpad = step::round_up(rows / 2, 32); p.Mrows = rows;
     return launch_gemm<false>(p, (hipStream_t)stream, "step_dft_fwd");
 }
 
@@ -553,6 +593,7 @@ extern "C" int step_dft_inv(const float* spec, const float* matt, const float* b
     STEP_REQUIRE(spec && matt && out, "step_dft_inv: null pointer");
     STEP_REQUIRE(N >= 1 && N <= 65535 && C >= 8 && C % 8 == 0 && C / 8 <= 65535 && T_out >= 1 && rows_in >= 32 && rows_in % 32 == 0,
                  "step_dft_inv: bad shape N=%d C=%d rows=%d T=%d", N, C, rows_in, T_out);
+    STEP_REQUIRE((size_t)C * T_out * 64 < (1ull << 31) && (size_t)rows_in * C * 64 < (1ull << 31), "step_dft_inv: sample too large");
     DgParams p{};
     STEP_REQUIRE((out_scale == nullptr) == (out_shift == nullptr) && (res_scale == nullptr) == (res_shift == nullptr),
                  "step_dft_inv: scale/shift must come in pairs");
@@ -560,7 +601,7 @@ extern "C" int step_dft_inv(const float* spec, const float* matt, const float* b
     p.in = spec; p.matt = matt; p.bias = bias; p.out = out;
     p.out_scale = out_scale; p.out_shift = out_shift; p.res = res; p.res_scale = res_scale; p.res_shift = res_shift;
     p.out_relu = out_relu;
-    p.N = N; p.C = C; p.K = rows_in; p.Kpad = rows_in; p.Mpad = step::round_up(T_out, 32); p.Mrows = T_out;
+    p.N = N; p.C = C; p.K = rows_in; p.Kpad = rows_in; p.Mpad = step::round_up((T_out + 1) / 2, 32); p.Mrows = T_out;
     const int groups = step_dft_groups(T_out);
     if (sums) {
         const size_t need = (size_t)N * groups * C * 2 * sizeof(double);

@@ -34,11 +34,11 @@ def geometry(T, Kt):
     return rows, rows // 2, rows - 1            # rows = 2 NF, NF, L
 
 
-def _tile(m, rows_out, device):
-    """[K][rows_out] float64 (k-major) -> the kernels' layout [groups][Kpad][32][mgp] float32 on the device"""
+def _tile(m, rows_out, inverse):
+    """[K][rows_out] float64 (k-major) -> the kernels' layout [groups][Kpad][32][mgp] float64 (step_dft_table_geom)"""
     import ctypes
     mgp, groups = ctypes.c_int(0), ctypes.c_int(0)
-    mg = _lib.load().step_dft_table_geom(rows_out, ctypes.byref(mgp), ctypes.byref(groups))
+    mg = _lib.load().step_dft_table_geom(rows_out, int(inverse), ctypes.byref(mgp), ctypes.byref(groups))
     mgp, groups = mgp.value, groups.value
     K = m.shape[0]
     kpad = (K + 15) // 16 * 16
@@ -47,54 +47,69 @@ def _tile(m, rows_out, device):
     t = full.view(kpad, groups, mg, 32).permute(1, 0, 3, 2)             # [groups][kpad][32][mg]
     out = torch.zeros(groups, kpad, 32, mgp, dtype=torch.float64)
     out[..., :mg] = t
-    return out.to(torch.float32).to(device).contiguous()
+    return out
 
 
-def _angles(a, b, L):
-    """2 pi (a b mod L) / L for integer grids a (column) and b (row), float64"""
-    prod = torch.remainder(a.to(torch.int64)[:, None] * b.to(torch.int64)[None, :], L).to(torch.float64)
-    return prod * (2.0 * math.pi / L)
+def _angles2(a, b, L):
+    """2 pi (a b mod 2L) / (2L) for integer grids a (rows) and b (columns): angles in half steps of the grid, float64"""
+    prod = torch.remainder(a.to(torch.int64)[:, None] * b.to(torch.int64)[None, :], 2 * L).to(torch.float64)
+    return prod * (math.pi / L)
+
+
+def centre2(K, step):
+    """twice the time origin of a K-sample signal taken at frames step * k: its frames are paired about
+    step * (ceil(K / 2) - 1/2) (csrc/tcn_dft.hip), and its spectrum is taken about that point"""
+    return step * (2 * ((K + 1) // 2) - 1)
 
 
 def fwd_matrix(K, step, T, Kt, device):
-    """k-major transform matrix for K samples taken at frames step * k of a length-T grid: [round_up(K,16)][stride],
-    column f < NF: cos(2 pi f step k / L), column NF + f: -sin(...); tiled by _tile"""
+    """transform matrix for K samples taken at frames step * k of a length-T grid, in the half-size form: pairs
+    j < ceil(K/2) of frames about the centre; cos(2 pi f step (j + 1/2) / L) rows (applied to the pair sums) tiled by
+    _tile, then the -sin(...) rows (applied to the pair differences)"""
     key = ("fwd", K, step, T, Kt, str(device))
     if key not in _TABLES:
         rows, NF, L = geometry(T, Kt)
-        ang = _angles(torch.arange(K) * step, torch.arange(NF), L)          # [K][NF]
-        _TABLES[key] = _tile(torch.cat((torch.cos(ang), -torch.sin(ang)), dim=1), rows, device)
+        Kh = (K + 1) // 2
+        ang = _angles2(step * (2 * torch.arange(Kh) + 1), torch.arange(NF), L)          # [Kh][NF]
+        t = torch.cat((_tile(torch.cos(ang), NF, False), _tile(-torch.sin(ang), NF, False)), dim=0)
+        _TABLES[key] = t.to(torch.float32).to(device).contiguous()
     return _TABLES[key]
 
 
 def inv_matrix(T_out, step, T, Kt, device):
-    """k-major inverse matrix onto frames step * t, t < T_out: [rows][stride], row f < NF: kap_f / L cos(2 pi f step t / L),
-    row NF + f: -kap_f / L sin(...); kap_0 = 1, else 2 (L is odd: no Nyquist bin)"""
+    """inverse matrix onto the pairs j < ceil(T_out/2) of frames step * t about their centre: k < NF (real rows of the
+    spectrum): kap_f / L cos(2 pi f step (j + 1/2) / L) -> E[j]; k >= NF: -kap_f / L sin(...) -> O[j]; the frames are
+    E + O and E - O.  kap_0 = 1, else 2 (L is odd: no Nyquist bin)"""
     key = ("inv", T_out, step, T, Kt, str(device))
     if key not in _TABLES:
         rows, NF, L = geometry(T, Kt)
-        ang = _angles(torch.arange(NF), torch.arange(T_out) * step, L)      # [NF][T_out]
+        Th = (T_out + 1) // 2
+        ang = _angles2(torch.arange(NF), step * (2 * torch.arange(Th) + 1), L)          # [NF][Th]
         kap = torch.full((NF, 1), 2.0 / L, dtype=torch.float64)
         kap[0, 0] = 1.0 / L
-        _TABLES[key] = _tile(torch.cat((kap * torch.cos(ang), -kap * torch.sin(ang)), dim=0), T_out, device)
+        m = torch.cat((kap * torch.cos(ang), -kap * torch.sin(ang)), dim=0)
+        _TABLES[key] = _tile(m, Th, True).to(torch.float32).to(device).contiguous()
     return _TABLES[key]
 
 
-def tap_tables(T, Kt, device):
-    """tc / ts [NF][Kt]: cos / sin of 2 pi f (j - P) / L"""
-    key = ("taps", T, Kt, str(device))
+def tap_tables(T, Kt, T_out, stride, device):
+    """tc / ts [NF][Kt]: cos / sin of 2 pi f (j - P + delta) / L; delta = the output's time origin minus the input's
+    (0 at stride 1, -1/2 at stride 2 with even T): the phase between the two spectra lives in the weights"""
+    d2 = centre2(T_out, stride) - centre2(T, 1)
+    key = ("taps", T, Kt, d2, str(device))
     if key not in _TABLES:
         rows, NF, L = geometry(T, Kt)
-        ang = _angles(torch.arange(NF), torch.arange(Kt) - (Kt - 1) // 2, L)
+        ang = _angles2(torch.arange(NF), 2 * (torch.arange(Kt) - (Kt - 1) // 2) + d2, L)
         _TABLES[key] = (torch.cos(ang).to(torch.float32).to(device).contiguous(),
                         torch.sin(ang).to(torch.float32).to(device).contiguous())
     return _TABLES[key]
 
 
-def weight_spectrum(w, C, T, Kt, transposed):
-    """(forward, backward) mixing matrices [NF][2C][2C] of the taps w (Co,Ci,Kt,1) [or (Ci,Co,Kt,1) when transposed]"""
+def weight_spectrum(w, C, T, Kt, transposed, T_out=None, stride=1):
+    """(forward, backward) mixing matrices [NF][2C][2C] of the taps w (Co,Ci,Kt,1) [or (Ci,Co,Kt,1) when transposed]
+    for a conv from T frames to T_out frames at `stride`"""
     rows, NF, L = geometry(T, Kt)
-    tc, ts = tap_tables(T, Kt, w.device)
+    tc, ts = tap_tables(T, Kt, T if T_out is None else T_out, stride, w.device)
     wf = torch.empty(NF * 4 * C * C, dtype=torch.float32, device=w.device)
     wb = torch.empty_like(wf)
     _lib.call("step_dft_wspec", w, tc, ts, wf, wb, C, C, NF, Kt, int(transposed))
@@ -147,9 +162,9 @@ def conv_dgrad(sdu, wb, T, Kt):
     return inverse(mix(sdu, wb, C), None, T, 1, T, Kt)
 
 
-def conv_wgrad(sdu, sa, T, Kt, transposed, wshape):
+def conv_wgrad(sdu, sa, T, Kt, transposed, wshape, T_out=None, stride=1):
     N, rows, C, V = sa.shape
-    tc, ts = tap_tables(T, Kt, sa.device)
+    tc, ts = tap_tables(T, Kt, T if T_out is None else T_out, stride, sa.device)
     dw = torch.empty(wshape, dtype=torch.float32, device=sa.device)
     db = torch.empty(C, dtype=torch.float32, device=sa.device)
     nb = _lib.query("step_dft_wgrad_ws_bytes", N, C, C, rows // 2)

@@ -424,7 +424,7 @@ class StGcnBlockFn(torch.autograd.Function):
         use_dft = s.dft == "force" or (s.dft == "auto" and _dft_mod.preferred(Co, Kt, T, To))
         if use_dft:
             # frequency domain: the spectrum of relu(bn1(y)) is kept for the weight gradient
-            wf_dft, wb_dft = _dft_mod.weight_spectrum(tcn_w, Co, T, Kt, s.transposed)
+            wf_dft, wb_dft = _dft_mod.weight_spectrum(tcn_w, Co, T, Kt, s.transposed, To, st)
             usums = torch.empty(2 * Co + 1, dtype=torch.float64, device=dev) if (training and _FUSED_STATS) else None
             u, sa = _dft_mod.conv_forward(y, s1, h1, True, wf_dft, tcn_b, To, st, Kt, usums)
             del wf_dft
@@ -512,8 +512,8 @@ class StGcnBlockFn(torch.autograd.Function):
             res_t = x
         if s.dft == "force" or (s.dft == "auto" and _dft_mod.preferred(Co, Kt, T, To)):
             # frequency domain: the weights' spectrum is cached per parameter version and sequence length
-            wf_dft = cached(c, "wf_dft", tensor_key(tcn_w) + (T, int(s.transposed)),
-                            lambda: _dft_mod.weight_spectrum(tcn_w, Co, T, Kt, s.transposed)[0])
+            wf_dft = cached(c, "wf_dft", tensor_key(tcn_w) + (T, To, st, int(s.transposed)),
+                            lambda: _dft_mod.weight_spectrum(tcn_w, Co, T, Kt, s.transposed, To, st)[0])
             out, _ = _dft_mod.conv_forward(y, s1, h1, True, wf_dft, tcn_b, To, st, Kt,
                                            epilogue=(s2, h2, res_t, sr, hr, True))
             return out
@@ -547,7 +547,7 @@ class StGcnBlockFn(torch.autograd.Function):
         if sa is not None:
             sdu = _dft_mod.transform(du, None, None, False, st, T, Kt)
             del du
-            dtw, dtb = _dft_mod.conv_wgrad(sdu, sa, T, Kt, s.transposed, tuple(tcn_w.shape))
+            dtw, dtb = _dft_mod.conv_wgrad(sdu, sa, T, Kt, s.transposed, tuple(tcn_w.shape), To, st)
             da = _dft_mod.conv_dgrad(sdu, wb_dft, T, Kt)
             del sdu
         else:

@@ -33,7 +33,7 @@ def test_dft_conv_forward_dgrad_wgrad_vs_oracle(C, stride, T, N, tr, Kt):
     da64, dw64, db64 = torch.autograd.grad(u64, (a64, w64, b64), du.double())
 
     yd, wd, bd, scd, shd, dud = (t.to(D) for t in (y, w, b, sc, sh, du))
-    wf, wb = dft.weight_spectrum(wd, C, T, Kt, tr)
+    wf, wb = dft.weight_spectrum(wd, C, T, Kt, tr, To, stride)
     sums = torch.zeros(2 * C + 1, dtype=torch.float64, device=D)
     u, sa = dft.conv_forward(yd, scd, shd, True, wf, bd, To, stride, Kt, sums)
     assert_close(u, u64, 1e-4, "u")
@@ -44,7 +44,7 @@ def test_dft_conv_forward_dgrad_wgrad_vs_oracle(C, stride, T, N, tr, Kt):
     sdu = dft.transform(dud, None, None, False, stride, T, Kt)
     da = dft.conv_dgrad(sdu, wb, T, Kt)
     assert_close(da, da64, 1e-4, "da")
-    dw, db = dft.conv_wgrad(sdu, sa, T, Kt, tr, tuple(w.shape))
+    dw, db = dft.conv_wgrad(sdu, sa, T, Kt, tr, tuple(w.shape), To, stride)
     assert_close(dw, dw64, 1e-4, "dw")
     assert_close(db, db64, 1e-4, "db")
     # no statistics asked, no activation: the plain paths

@@ -44,7 +44,7 @@ def main():
     b = torch.zeros(c, device=d)
     sc, sh = torch.ones(c, device=d), torch.zeros(c, device=d)
     rows, NF, L = dft.geometry(t, kt)
-    wf, wb = dft.weight_spectrum(w, c, t, kt, False)
+    wf, wb = dft.weight_spectrum(w, c, t, kt, False, to, s)
     sums = torch.zeros(2 * c + 1, dtype=torch.float64, device=d)
     want = lambda *names: not a.only or any(a.only in x for x in names)      # set up only what the chosen stages read
     sa = dft.transform(y, sc, sh, True, 1, t, kt) if want("fwd: mix", "bwd: wgrad", "fwd: inverse(+stats)") or not a.only else None
@@ -53,14 +53,14 @@ def main():
     smb = dft.mix(sdu, wb, c) if want("bwd: inverse") else None
     fl = 2.0 * c * c * kt * to * 16 * n
     stages = [
-        ("wspec", lambda: dft.weight_spectrum(w, c, t, kt, False), 0),
+        ("wspec", lambda: dft.weight_spectrum(w, c, t, kt, False, to, s), 0),
         ("fwd: transform(a)", lambda: dft.transform(y, sc, sh, True, 1, t, kt), 2.0 * rows * t * c * 16 * n),
         ("fwd: mix", lambda: dft.mix(sa, wf, c), 2.0 * 4 * c * c * 16 * NF * n),
         ("fwd: inverse(+stats)", lambda: dft.inverse(sm, b, to, s, t, kt, sums), 2.0 * rows * to * c * 16 * n),
         ("bwd: transform(du)", lambda: dft.transform(du, None, None, False, s, t, kt), 2.0 * rows * to * c * 16 * n),
         ("bwd: mix", lambda: dft.mix(sdu, wb, c), 2.0 * 4 * c * c * 16 * NF * n),
         ("bwd: inverse", lambda: dft.inverse(smb, None, t, 1, t, kt), 2.0 * rows * t * c * 16 * n),
-        ("bwd: wgrad", lambda: dft.conv_wgrad(sdu, sa, t, kt, False, tuple(w.shape)), 2.0 * 4 * c * c * 16 * NF * n),
+        ("bwd: wgrad", lambda: dft.conv_wgrad(sdu, sa, t, kt, False, tuple(w.shape), to, s), 2.0 * 4 * c * c * 16 * NF * n),
     ]
     tot = {"fwd": 0.0, "bwd": 0.0}
     print("C=%d s=%d T=%d N=%d Kt=%d: rows=%d L=%d, spectrum %.2f GB" % (c, s, t, n, kt, rows, L, n * rows * c * 64 / 1e9))
