@@ -25,6 +25,7 @@
 
 namespace {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 static __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_n(const float* base, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes, 0x00020000);
 }
@@ -37,19 +38,25 @@ static __device__ __forceinline__ int rowmap(int r, int half) { return (r & 3) +
 // conv's input and output is a phase folded into the weight spectrum and the tap tables, step_amd/dft.py), so that
 //   Re X[f] = SUM_j (x[hi] + x[lo]) cos(th_fj),   Im X[f] = - SUM_j (x[hi] - x[lo]) sin(th_fj),   th_fj = 2 pi f s (j + 1/2) / L
 //   x[hi], x[lo] = E[j] +- O[j],   E[j] = SUM_f kap_f / L cos(th_fj) Re X[f],   O[j] = - SUM_f kap_f / L sin(th_fj) Im X[f]
-//   INV == 0 (to the frequency domain): row-tile groups [0, gh) are the cos rows on the pair sums, [gh, 2 gh) the sin
-//            rows on the pair differences; In(n,k,c,v) = act(in[n][c][k][v]),  Out = S[n][m][c][v]
+//   INV == 0 (to the frequency domain): a block takes MG row tiles of the cos half (on the pair sums) and the same MG
+//            tiles of the sin half (on the pair differences): one read of the frames feeds both;
+//            In(n,k,c,v) = act(in[n][c][k][v]),  Out = S[n][m][c][v]
 //   INV == 1 (back): rows = pairs j; the first NF k (Re rows of S) accumulate E, the last NF (Im rows) O; the epilogue
 //            writes frames hi and lo: Out = out[n][c][frame][v] (+ bias, statistics, eval-mode tail)
+//            (taking the real and the imaginary row of a bin in the same k-step, as the forward form does with its pair
+//            sums and differences, measured 20 % slower: two distant row streams per wave instead of one)
 // The matrix is stored k-major and tiled (step_dft_table_geom); rows past the real extent and k past K are zero.
 // Block = 4 waves = (sample, 8 channels = 4 column tiles of 2 channels x 16 joints, group of MG row tiles); wave w owns
-// column tile w and all MG row tiles.  The matrix streams through LDS in chunks of KC = 16 k (double-buffered, one
-// barrier per chunk); the B operand is the lane's own 4-byte loads (64 contiguous bytes per 16 lanes), a chunk ahead.
+// column tile w and all row tiles of the group.  The matrix streams through LDS in chunks of KC = 16 k (double-buffered,
+// one barrier per chunk); the B operand is the lane's own 4-byte loads (64 contiguous bytes per 16 lanes), a chunk ahead.
+// (A persistent form - one block of 8 waves per CU, the whole matrix resident in LDS, waves walking the column tiles
+// without a barrier - measured 5-25 % SLOWER on the same box at every shape of the model, with or without its stores,
+// staggered or not; so did three blocks per CU.  Not kept.)
 constexpr int KC = 16;
 
 struct DgParams {
     const float* in;
-    const float* matt;       // [groups][Kpad][32][MGP]: element (g, k, l, i) = M[row g * MG * 32 + i * 32 + l][k] (step_dft_table_geom)
+    const float* matt;       // [groups][Kpad][slots WP x 32]: per k the row tiles in groups of four, [q][32 rows][4 tiles], then a last pair [32][2] (step_dft_table_geom)
     const float* in_scale;   // INV == 0: BN + ReLU on the load (per channel), or null
     const float* in_shift;
     const float* bias;       // INV == 1: per channel, or null
@@ -63,28 +70,32 @@ struct DgParams {
     double* stat_part;       // INV == 1: [N * groups][C][2] partial SUM out, SUM out^2, or null
     int in_relu;
     int N, C, K, Kpad, Mpad, Mrows;   // INV == 0: K frames, Kpad = round_up(ceil(K/2), KC), Mrows = 2 NF; INV == 1: K = Kpad = 2 NF, Mrows = T_out
-    int gh;                           // INV == 0: row-tile groups per half (cos | sin)
 };
+
+// slots per k in the table for W row tiles: fours, then a pair (3 -> 4)
+constexpr int table_slots(int W) { return (W % 4 == 0) ? W : (W % 4 == 2 ? W : W + 1); }
 
 template <int MG, bool INV>
 __global__ __launch_bounds__(256, 2) void dft_gemm_kernel(DgParams p) {
     constexpr int MGR = MG * 32;
-    constexpr int NACC = INV ? 2 * MG : MG;            // INV: E tiles, then O tiles
-    // matrix chunk in LDS: [k][32 rows-in-tile][MGP tiles] - a lane's A values of all its row tiles for one k are
-    // contiguous, one ds_read_b128 per four tiles instead of a 4-byte read per MFMA (lane stride 16 or 48 bytes: the
-    // 16-byte reads of 8 consecutive lanes cover all 32 banks once)
-    constexpr int MGP = MG <= 4 ? 4 : 12;
-    constexpr int CHUNK = KC * 32 * MGP;
-    __shared__ __attribute__((aligned(16))) float fbuf[2][CHUNK];
+    constexpr int NACC = 2 * MG;                       // INV: E tiles, then O tiles; else cos tiles, then sin tiles
+    constexpr int TABW = INV ? MG : 2 * MG;            // row tiles per k in the table (INV == 0: cos, then sin)
+    constexpr int WP = table_slots(TABW);
+    constexpr int NQ = WP / 4;                         // 16-byte reads per k: lanes 16 bytes apart, conflict-free
+    constexpr bool PAIR = (WP % 4) == 2;               // + one 8-byte read
+    constexpr int KSTR = WP * 32;                      // floats per k
+    constexpr int CHUNK = KC * KSTR;
+    __shared__ __attribute__((aligned(16))) float fbuf[2 * CHUNK];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, half = lane >> 5;
     const int cpar = l31 >> 4, v = l31 & 15;
     const int g = blockIdx.x;                           // row-tile group (fastest: groups share the B operand in L2)
-    const int cg = blockIdx.y, n = blockIdx.z;
-    const int c = cg * 8 + wave * 2 + cpar;
-    const int odd = !INV && g >= p.gh;                  // INV == 0: this group holds sin rows (on the pair differences)
-    const int m0 = (INV ? g : g - odd * p.gh) * MGR;    // first row of the group within its half / first pair
+    const int m0 = g * MGR;                             // first row of the group within its half / first pair
+    const int nchunk = p.Kpad / KC;
+
+    const int n = blockIdx.z;
+    const int c = blockIdx.y * 8 + wave * 2 + cpar;
 
     // B operand addressing: descriptor on the sample, lane offsets, uniform k offsets
     const size_t sample = (size_t)p.C * p.K * 16;
@@ -98,7 +109,6 @@ __global__ __launch_bounds__(256, 2) void dft_gemm_kernel(DgParams p) {
     const bool act = !INV && p.in_scale != nullptr;
     if (act) { sc = p.in_scale[c]; sh = p.in_shift[c]; }
     const float lo = (!INV && p.in_relu) ? 0.f : -__builtin_inff();
-    const float sg = odd ? -1.f : 1.f;
     const int nhi = p.K - Kh;                           // pairs whose hi frame exists (K odd: one fewer than Kh)
 
     f32x16 acc[NACC];
@@ -107,22 +117,25 @@ __global__ __launch_bounds__(256, 2) void dft_gemm_kernel(DgParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
-    const int nchunk = p.Kpad / KC;
-    // the table is laid out [group][k][32][MGP] (step_amd/dft.py), so a chunk is one contiguous run: a linear copy
-    constexpr int FPT = CHUNK / 4 / 256;
-    static_assert(CHUNK % 1024 == 0, "chunk copy");
+    // a chunk of the table is one contiguous run: a linear copy, registers in between
+    constexpr int FPT = (CHUNK / 4 + 255) / 256;
     f32x4 freg[FPT];
-    const float* fsrc = p.matt + (size_t)g * p.Kpad * 32 * MGP + tid * 4;
+    const float* fsrc = p.matt + (size_t)g * p.Kpad * KSTR + tid * 4;
     auto load_f = [&](int kc) {
 #pragma unroll
-        for (int i = 0; i < FPT; ++i) freg[i] = *reinterpret_cast<const f32x4*>(fsrc + (size_t)kc * CHUNK + i * 1024);
+        for (int i = 0; i < FPT; ++i)
+            if (CHUNK % 1024 == 0 || tid * 4 + i * 1024 < CHUNK)
+                freg[i] = *reinterpret_cast<const f32x4*>(fsrc + (size_t)kc * CHUNK + i * 1024);
     };
     auto store_f = [&](int b) {
 #pragma unroll
-        for (int i = 0; i < FPT; ++i) *reinterpret_cast<f32x4*>(&fbuf[b][tid * 4 + i * 1024]) = freg[i];
+        for (int i = 0; i < FPT; ++i)
+            if (CHUNK % 1024 == 0 || tid * 4 + i * 1024 < CHUNK)
+                *reinterpret_cast<f32x4*>(&fbuf[b * CHUNK + tid * 4 + i * 1024]) = freg[i];
     };
-    float bcur[KC / 2], bnxt[KC / 2];
-    auto load_b = [&](int kc, float (&b)[KC / 2]) {
+    constexpr int NB = INV ? KC / 2 : KC;              // INV == 0: pair sums, then pair differences
+    float bcur[NB], bnxt[NB];
+    auto load_b = [&](int kc, float (&b)[NB]) {
 #pragma unroll
         for (int ks = 0; ks < KC / 2; ++ks) {
             const int k = kc * KC + 2 * ks;                                  // (+ half: in the lane offsets)
@@ -135,27 +148,40 @@ __global__ __launch_bounds__(256, 2) void dft_gemm_kernel(DgParams p) {
                 xh = fmaxf(xh, lo); xl = fmaxf(xl, lo);
                 xh = (k + half < nhi) ? xh : 0.f;                             // the odd frame out / k padding (the matrix is 0 there too)
                 xl = (k + half < Kh) ? xl : 0.f;
-                b[ks] = xh + sg * xl;
+                b[ks] = xh + xl;
+                b[KC / 2 + ks] = xh - xl;
             }
         }
     };
     auto chunk = [&](int kc, f32x16* A) {
         const bool more = kc + 1 < nchunk;
         if (more) { load_f(kc + 1); load_b(kc + 1, bnxt); }
-        const float* fb = fbuf[kc & 1] + (half * 32 + l31) * MGP;
+        const float* fb = fbuf + (kc & 1) * CHUNK + half * KSTR;
 #pragma unroll
         for (int ks = 0; ks < KC / 2; ++ks) {
-            f32x4 a[MGP / 4];
+            float a[WP];
 #pragma unroll
-            for (int q = 0; q < (MG + 3) / 4; ++q) a[q] = *reinterpret_cast<const f32x4*>(fb + (2 * ks) * 32 * MGP + q * 4);
+            for (int q = 0; q < NQ; ++q) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(fb + (2 * ks) * KSTR + q * 128 + l31 * 4);
+                a[4 * q] = t[0]; a[4 * q + 1] = t[1]; a[4 * q + 2] = t[2]; a[4 * q + 3] = t[3];
+            }
+            if constexpr (PAIR) {
+                const f32x2 t = *reinterpret_cast<const f32x2*>(fb + (2 * ks) * KSTR + NQ * 128 + l31 * 2);
+                a[4 * NQ] = t[0]; a[4 * NQ + 1] = t[1];
+            }
 #pragma unroll
             for (int i = 0; i < MG; ++i)
-                A[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i >> 2][i & 3], bcur[ks], A[i], 0, 0, 0);
+                A[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bcur[ks], A[i], 0, 0, 0);
+            if constexpr (!INV) {
+#pragma unroll
+                for (int i = MG; i < 2 * MG; ++i)
+                    A[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bcur[KC / 2 + ks], A[i], 0, 0, 0);
+            }
         }
         if (more) {
             store_f((kc + 1) & 1);
 #pragma unroll
-            for (int ks = 0; ks < KC / 2; ++ks) bcur[ks] = bnxt[ks];
+            for (int ks = 0; ks < NB; ++ks) bcur[ks] = bnxt[ks];
         }
         __syncthreads();
     };
@@ -173,18 +199,23 @@ __global__ __launch_bounds__(256, 2) void dft_gemm_kernel(DgParams p) {
     }
 
     if constexpr (!INV) {
-        // S[n][m][c][v]: 32 lanes (2 channels x 16 joints) write 128 contiguous bytes per row; the descriptor ends with
-        // this half's rows (NF is not a multiple of 32: the padding rows of the cos half must not land in the sin half)
+        // S[n][m][c][v]: 32 lanes (2 channels x 16 joints) write 128 contiguous bytes per row; the cos half's descriptor
+        // ends with its NF rows (NF is not a multiple of 32: its padding rows must not land in the sin half), the sin
+        // half's with the sample
         const int NF = p.Mrows >> 1;
         const size_t osample = (size_t)p.Mrows * p.C * 16;
-        const __amdgpu_buffer_rsrc_t ro = rsrc_n(p.out + (size_t)n * osample, (unsigned)((size_t)(odd + 1) * NF * p.C * 64));
         const unsigned rowb = (unsigned)p.C * 64u;
-        const unsigned ol = ((unsigned)(odd * NF + m0 + 4 * half) * (unsigned)p.C * 16u + (unsigned)c * 16u + v) * 4u;
+        const unsigned ol = ((unsigned)(m0 + 4 * half) * (unsigned)p.C * 16u + (unsigned)c * 16u + v) * 4u;
 #pragma unroll
-        for (int i = 0; i < MG; ++i)
+        for (int h = 0; h < 2; ++h) {
+            const __amdgpu_buffer_rsrc_t ro = rsrc_n(p.out + (size_t)n * osample, (unsigned)((size_t)(h + 1) * NF * p.C * 64));
+            const unsigned oh = ol + (unsigned)(h * NF) * rowb;
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                bstore(ro, ol + (unsigned)(i * 32 + (r & 3) + 8 * (r >> 2)) * rowb, 0u, acc[i][r]);
+            for (int i = 0; i < MG; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    bstore(ro, oh + (unsigned)(i * 32 + (r & 3) + 8 * (r >> 2)) * rowb, 0u, acc[h * MG + i][r]);
+        }
     } else {
         const float bia = p.bias ? p.bias[c] : 0.f;
         float osc = 1.f, osh = 0.f, rsc = 1.f, rsh = 0.f;
@@ -509,12 +540,12 @@ __global__ __launch_bounds__(256) void dft_wspec_kernel(const float* __restrict_
 }
 
 int pick_mg(int mtiles, bool inverse) {
-    // largest group that divides the tile count, else the one with the least padding; the inverse keeps two
-    // accumulator sets (E and O), so its groups stop at 4 tiles (128 accumulator registers)
+    // largest group that divides the tile count, else the one with the least padding; both directions keep two
+    // accumulator sets (cos | sin rows, E | O), so groups stop at 5 / 4 tiles (160 / 128 accumulator registers)
     if (mtiles <= 1) return 2;
-    const int cand_f[] = {9, 8, 5, 4, 3, 2}, cand_i[] = {4, 3, 2};
+    const int cand_f[] = {5, 4, 3, 2}, cand_i[] = {4, 3, 2};
     const int* cand = inverse ? cand_i : cand_f;
-    const int nc = inverse ? 3 : 6;
+    const int nc = inverse ? 3 : 4;
     for (int i = 0; i < nc; ++i)
         if (mtiles % cand[i] == 0) return cand[i];
     int best = cand[nc - 1], waste = 1 << 30;
@@ -531,13 +562,12 @@ int launch_gemm(DgParams p, hipStream_t st, const char* what) {
     const int mtiles = p.Mpad / 32;
     const int mg = pick_mg(mtiles, INV);
     const int groups = step::ceil_div(mtiles, mg);
-    p.gh = groups;
-    const dim3 grid((unsigned)(INV ? groups : 2 * groups), (unsigned)(p.C / 8), (unsigned)p.N);
+    const dim3 grid((unsigned)groups, (unsigned)(p.C / 8), (unsigned)p.N);
 #define DG_CASE(MGV) case MGV: hipLaunchKernelGGL((dft_gemm_kernel<MGV, INV>), grid, dim3(256), 0, st, p); return step::check_launch(what)
     if constexpr (INV) {
         switch (mg) { DG_CASE(2); DG_CASE(3); DG_CASE(4); default: break; }
     } else {
-        switch (mg) { DG_CASE(2); DG_CASE(3); DG_CASE(4); DG_CASE(5); DG_CASE(8); DG_CASE(9); default: break; }
+        switch (mg) { DG_CASE(2); DG_CASE(3); DG_CASE(4); DG_CASE(5); default: break; }
     }
 #undef DG_CASE
     step::set_error("%s: no kernel for %d row tiles", what, mtiles);
@@ -552,16 +582,18 @@ extern "C" int step_dft_rows(int T, int Kt) {
     return step::round_up(T + (Kt - 1) / 2 + 1, 32);
 }
 
-// layout of the matrices step_dft_fwd / step_dft_inv read.  `rows` = the matrix's output rows: NF for each half (cos,
+// layout of the matrices step_dft_fwd / step_dft_inv read (one layout for both kernel forms).  `rows` = the matrix's output rows: NF for each half (cos,
 // sin) of the forward matrix, ceil(T_out / 2) pairs for the inverse.  A matrix of `rows` rows is tiled
-// [groups][Kpad][32][mgp] floats, element (g, k, l, i) = M[row (g * mg + i) * 32 + l][k], zero where the row or k does not
-// exist (Kpad = round_up(ceil(K / 2), 16) forward, 2 NF inverse); the forward table is the cos half's tiling followed by
-// the sin half's.  Returns mg, *mgp = its padded extent (the kernels read 16 bytes at a time), *groups
+// [groups][Kpad][mgp x 32] floats: tile slot i of group g is M[row (g * mg + i) * 32 + l][k], zero where the row or k does
+// not exist (Kpad = round_up(ceil(K / 2), 16) forward, 2 NF inverse); in the forward table slots i < mg hold the cos
+// half's tiles and slots mg + i the sin half's.  Per k the slots are stored in fours, [q][l < 32][4], then (mgp % 4 == 2)
+// a last pair [l][2]: every LDS read is 16 (8) bytes per lane at a lane stride of 16 (8) bytes.  Returns mg, *mgp = the
+// slot count per k (3 tiles are padded to 4), *groups
 extern "C" int step_dft_table_geom(int rows, int inverse, int* mgp, int* groups) {
     const int mtiles = step::ceil_div(rows, 32);
     if (mtiles < 1) return 0;
     const int mg = pick_mg(mtiles, inverse != 0);
-    if (mgp) *mgp = mg <= 4 ? 4 : 12;
+    if (mgp) *mgp = table_slots(inverse ? mg : 2 * mg);
     if (groups) *groups = step::ceil_div(mtiles, mg);
     return mg;
 }

@@ -34,20 +34,26 @@ def geometry(T, Kt):
     return rows, rows // 2, rows - 1            # rows = 2 NF, NF, L
 
 
-def _tile(m, rows_out, inverse):
-    """[K][rows_out] float64 (k-major) -> the kernels' layout [groups][Kpad][32][mgp] float64 (step_dft_table_geom)"""
+def _tile(mats, rows_out, inverse):
+    """k-major float64 matrices [K][rows_out] -> the kernels' layout [groups][Kpad][slots x 32] (step_dft_table_geom):
+    one matrix for the inverse, (cos, sin) for the forward transform, whose tiles share a group (slots i and mg + i);
+    per k the slots go in fours [q][32][4], then a last pair [32][2]"""
     import ctypes
-    mgp, groups = ctypes.c_int(0), ctypes.c_int(0)
-    mg = _lib.load().step_dft_table_geom(rows_out, int(inverse), ctypes.byref(mgp), ctypes.byref(groups))
-    mgp, groups = mgp.value, groups.value
-    K = m.shape[0]
+    wp, groups = ctypes.c_int(0), ctypes.c_int(0)
+    mg = _lib.load().step_dft_table_geom(rows_out, int(inverse), ctypes.byref(wp), ctypes.byref(groups))
+    wp, groups = wp.value, groups.value
+    K = mats[0].shape[0]
     kpad = (K + 15) // 16 * 16
-    full = torch.zeros(kpad, groups * mg * 32, dtype=torch.float64)
-    full[:K, :m.shape[1]] = m
-    t = full.view(kpad, groups, mg, 32).permute(1, 0, 3, 2)             # [groups][kpad][32][mg]
-    out = torch.zeros(groups, kpad, 32, mgp, dtype=torch.float64)
-    out[..., :mg] = t
-    return out
+    slots = torch.zeros(groups, kpad, wp, 32, dtype=torch.float64)
+    for h, m in enumerate(mats):
+        full = torch.zeros(kpad, groups * mg * 32, dtype=torch.float64)
+        full[:K, :m.shape[1]] = m
+        slots[:, :, h * mg:(h + 1) * mg] = full.view(kpad, groups, mg, 32).permute(1, 0, 2, 3)     # [groups][kpad][mg][32]
+    nq = wp // 4
+    parts = [slots[:, :, :4 * nq].reshape(groups, kpad, nq, 4, 32).permute(0, 1, 2, 4, 3).reshape(groups, kpad, nq * 128)]
+    if wp % 4:
+        parts.append(slots[:, :, 4 * nq:].permute(0, 1, 3, 2).reshape(groups, kpad, 64))
+    return torch.cat(parts, dim=2)
 
 
 def _angles2(a, b, L):
@@ -65,13 +71,13 @@ def centre2(K, step):
 def fwd_matrix(K, step, T, Kt, device):
     """transform matrix for K samples taken at frames step * k of a length-T grid, in the half-size form: pairs
     j < ceil(K/2) of frames about the centre; cos(2 pi f step (j + 1/2) / L) rows (applied to the pair sums) tiled by
-    _tile, then the -sin(...) rows (applied to the pair differences)"""
+    and the -sin(...) rows (applied to the pair differences), tiled together by _tile"""
     key = ("fwd", K, step, T, Kt, str(device))
     if key not in _TABLES:
         rows, NF, L = geometry(T, Kt)
         Kh = (K + 1) // 2
         ang = _angles2(step * (2 * torch.arange(Kh) + 1), torch.arange(NF), L)          # [Kh][NF]
-        t = torch.cat((_tile(torch.cos(ang), NF, False), _tile(-torch.sin(ang), NF, False)), dim=0)
+        t = _tile((torch.cos(ang), -torch.sin(ang)), NF, False)
         _TABLES[key] = t.to(torch.float32).to(device).contiguous()
     return _TABLES[key]
 
@@ -88,7 +94,7 @@ def inv_matrix(T_out, step, T, Kt, device):
         kap = torch.full((NF, 1), 2.0 / L, dtype=torch.float64)
         kap[0, 0] = 1.0 / L
         m = torch.cat((kap * torch.cos(ang), -kap * torch.sin(ang)), dim=0)
-        _TABLES[key] = _tile(m, Th, True).to(torch.float32).to(device).contiguous()
+        _TABLES[key] = _tile((m,), Th, True).to(torch.float32).to(device).contiguous()
     return _TABLES[key]
 
 

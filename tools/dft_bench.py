@@ -54,12 +54,12 @@ def main():
     fl = 2.0 * c * c * kt * to * 16 * n
     stages = [
         ("wspec", lambda: dft.weight_spectrum(w, c, t, kt, False, to, s), 0),
-        ("fwd: transform(a)", lambda: dft.transform(y, sc, sh, True, 1, t, kt), 2.0 * rows * t * c * 16 * n),
+        ("fwd: transform(a)", lambda: dft.transform(y, sc, sh, True, 1, t, kt), 1.0 * rows * t * c * 16 * n),
         ("fwd: mix", lambda: dft.mix(sa, wf, c), 2.0 * 4 * c * c * 16 * NF * n),
-        ("fwd: inverse(+stats)", lambda: dft.inverse(sm, b, to, s, t, kt, sums), 2.0 * rows * to * c * 16 * n),
-        ("bwd: transform(du)", lambda: dft.transform(du, None, None, False, s, t, kt), 2.0 * rows * to * c * 16 * n),
+        ("fwd: inverse(+stats)", lambda: dft.inverse(sm, b, to, s, t, kt, sums), 1.0 * rows * to * c * 16 * n),
+        ("bwd: transform(du)", lambda: dft.transform(du, None, None, False, s, t, kt), 1.0 * rows * to * c * 16 * n),
         ("bwd: mix", lambda: dft.mix(sdu, wb, c), 2.0 * 4 * c * c * 16 * NF * n),
-        ("bwd: inverse", lambda: dft.inverse(smb, None, t, 1, t, kt), 2.0 * rows * t * c * 16 * n),
+        ("bwd: inverse", lambda: dft.inverse(smb, None, t, 1, t, kt), 1.0 * rows * t * c * 16 * n),
         ("bwd: wgrad", lambda: dft.conv_wgrad(sdu, sa, t, kt, False, tuple(w.shape), to, s), 2.0 * 4 * c * c * 16 * NF * n),
     ]
     tot = {"fwd": 0.0, "bwd": 0.0}
@@ -71,8 +71,9 @@ def main():
         if name[:3] in tot:
             tot[name[:3]] += ms
         print("  %-22s %8.3f ms  %7.1f TFLOP/s executed" % (name, ms, flops / ms / 1e9), flush=True)
-    print("  forward %.2f ms, backward (dgrad + wgrad) %.2f ms; direct-conv FLOPs per pass %.2f T -> %.0f / %.0f TFLOP/s equivalent"
-          % (tot["fwd"], tot["bwd"], fl / 1e12, fl / tot["fwd"] / 1e9, 2 * fl / tot["bwd"] / 1e9))
+    if not a.only:
+        print("  forward %.2f ms, backward (dgrad + wgrad) %.2f ms; direct-conv FLOPs per pass %.2f T -> %.0f / %.0f TFLOP/s equivalent"
+              % (tot["fwd"], tot["bwd"], fl / 1e12, fl / tot["fwd"] / 1e9, 2 * fl / tot["bwd"] / 1e9))
     if kt == 75 and not a.no_direct:
         wp = ops.tcn_pack(w, c, c, kt, s, 0)
         wpd = ops.tcn_pack(w, c, c, kt, s, 2)
