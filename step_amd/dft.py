@@ -18,15 +18,15 @@ def supported(C, Kt):
 
 
 def preferred(C, Kt, T, T_out):
-    """cost model for the default fp32 mode: the frequency-domain path when its multiply-adds (two transforms per pass
-    + the per-bin mixing) are under 60 % of the direct kernels' (75 taps at T <= ~600: 4-10x fewer; T = 1024 or 9 taps:
-    the direct kernels win)"""
+    """cost model for the default fp32 mode: the frequency-domain path when its multiply-adds (two half-size transforms
+    per pass + the per-bin mixing) are under 60 % of the direct kernels' - its GEMMs run at 0.5-0.65 of the fp32 MFMA
+    peak, the direct kernels at 0.88 (75 taps: 7-14x fewer at T = 120 / 240, 2-4x at T = 1024; 9 taps: the direct kernels)"""
     if not supported(C, Kt):
         return False
     rows = _lib.query("step_dft_rows", T, Kt)
-    cost_dft = 2.0 * rows * (T + T_out) * C * 16 + 8.0 * C * C * 16 * (rows // 2)
+    cost_dft = 1.0 * rows * (T + T_out) * C * 16 + 8.0 * C * C * 16 * (rows // 2)
     cost_direct = 2.0 * C * C * Kt * T_out * 16
-    return cost_dft < 0.6 * cost_direct
+    return cost_dft < (0.6 if Kt >= 25 else 0.4) * cost_direct       # (short kernels: only with a wide margin)
 
 
 def geometry(T, Kt):
