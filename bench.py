@@ -111,7 +111,8 @@ def time_kernels(n, t, device, reps=3, bf16=False, blocks=None, tag="b"):
 def time_dft_kernels(n, t, device, reps=3):
     """HIP-event timing of every stage of the frequency-domain temporal conv (the default fp32 path; step_amd/dft.py,
     csrc/tcn_dft.hip) for the three blocks of the step, each with the FLOPs its GEMM executes:
-    transform / inverse 2 * rows * frames * C * 16 per sequence, mixing and weight gradient 2 * (2C)^2 * 16 * NF."""
+    transform / inverse rows * frames * C * 16 per sequence (half-size forms: rows x frames / 2 multiply-adds per column),
+    mixing and weight gradient 2 * (2C)^2 * 16 * NF."""
     from step_amd import dft
     out = []
     g = torch.Generator().manual_seed(11)
@@ -132,12 +133,12 @@ def time_dft_kernels(n, t, device, reps=3):
         fmix = 2.0 * 4 * c * c * 16 * nf * n
         spec_bytes = 4.0 * sa.numel()
         stages = [
-            ("dft_transform", lambda: dft.transform(y, sc, sh, True, 1, tin, 75), 2.0 * rows * tin * c * 16 * n, 4.0 * y.numel() + spec_bytes),
+            ("dft_transform", lambda: dft.transform(y, sc, sh, True, 1, tin, 75), 1.0 * rows * tin * c * 16 * n, 4.0 * y.numel() + spec_bytes),
             ("dft_mix", lambda: dft.mix(sa, wf, c), fmix, 2 * spec_bytes),
-            ("dft_inverse", lambda: dft.inverse(sm, b, tout, s, tin, 75, sums), 2.0 * rows * tout * c * 16 * n, spec_bytes + 4.0 * du.numel()),
-            ("dft_transform_dout", lambda: dft.transform(du, None, None, False, s, tin, 75), 2.0 * rows * tout * c * 16 * n, 4.0 * du.numel() + spec_bytes),
+            ("dft_inverse", lambda: dft.inverse(sm, b, tout, s, tin, 75, sums), 1.0 * rows * tout * c * 16 * n, spec_bytes + 4.0 * du.numel()),
+            ("dft_transform_dout", lambda: dft.transform(du, None, None, False, s, tin, 75), 1.0 * rows * tout * c * 16 * n, 4.0 * du.numel() + spec_bytes),
             ("dft_mix_bwd", lambda: dft.mix(sdu, wb, c), fmix, 2 * spec_bytes),
-            ("dft_inverse_bwd", lambda: dft.inverse(smb, None, tin, 1, tin, 75), 2.0 * rows * tin * c * 16 * n, spec_bytes + 4.0 * y.numel()),
+            ("dft_inverse_bwd", lambda: dft.inverse(smb, None, tin, 1, tin, 75), 1.0 * rows * tin * c * 16 * n, spec_bytes + 4.0 * y.numel()),
             ("dft_wgrad", lambda: dft.conv_wgrad(sdu, sa, tin, 75, False, tuple(w.shape), tout, s), fmix, 2 * spec_bytes),
         ]
         for name, fn, fl, nbytes in stages:
@@ -287,8 +288,8 @@ def model_flops_per_sequence_dft(t, kt=75, k=3):
         rows, nf, _ = dft.geometry(tt, kt)
         gcn = 2.0 * ci * k * co * tt * 16 + 2.0 * k * co * tt * 16 * 16 + (2.0 * ci * co * to * 16 if (ci != co or s != 1) else 0.0)
         mixf = 2.0 * 4 * co * co * 16 * nf
-        f = 2.0 * rows * tt * co * 16 + mixf + 2.0 * rows * to * co * 16
-        b = 2.0 * rows * to * co * 16 + mixf + 2.0 * rows * tt * co * 16 + mixf
+        f = 1.0 * rows * tt * co * 16 + mixf + 1.0 * rows * to * co * 16
+        b = 1.0 * rows * to * co * 16 + mixf + 1.0 * rows * tt * co * 16 + mixf
         fwd += gcn + f
         both += 3.0 * gcn + f + b
         ci, tt = co, to

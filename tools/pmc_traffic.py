@@ -81,7 +81,7 @@ def main(src="gpurun_out"):
     # the run and are therefore used only for the stage whose launches all have one shape.
     rows = (T + 38 + 31) // 32 * 32
     spec = 4 * N * rows * C * 16
-    for key, st, templ, alg_d in (("dft_transform_b1", "tr", "dft_gemm_kernel<9, false>", 4 * N * C * T * 16 + spec),
+    for key, st, templ, alg_d in (("dft_transform_b1", "tr", "dft_gemm_kernel<5, false>", 4 * N * C * T * 16 + spec),
                                   ("dft_inverse_bwd_b1", "ib", "dft_gemm_kernel<4, true>", spec + 4 * N * C * T * 16)):
         try:
             mfd, fed, wrd = (read(os.path.join(ROOT, src, "pmc_dft_%s_%s.txt" % (st, k))) for k in ("mfma", "fetch", "write"))
