@@ -159,6 +159,7 @@ __global__ __launch_bounds__(256, 2) void dft_gemm_kernel(DgParams p) {
         const float* fb = fbuf + (kc & 1) * CHUNK + half * KSTR;
 #pragma unroll
         for (int ks = 0; ks < KC / 2; ++ks) {
+            if (!INV && kc * KC + 2 * ks >= Kh) break;                       // k padding of the last chunk (uniform)
             float a[WP];
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
