@@ -112,7 +112,7 @@ def time_dft_kernels(n, t, device, reps=3):
     """HIP-event timing of every stage of the frequency-domain temporal conv (the default fp32 path; step_amd/dft.py,
     csrc/tcn_dft.hip) for the three blocks of the step, each with the FLOPs its GEMM executes:
     transform / inverse rows * frames * C * 16 per sequence (half-size forms: rows x frames / 2 multiply-adds per column),
-    mixing and weight gradient 2 * (2C)^2 * 16 * NF."""
+    mixing and weight gradient 2 * 3 C^2 * 16 * NF (complex products as three real ones)."""
     from step_amd import dft
     out = []
     g = torch.Generator().manual_seed(11)
@@ -130,7 +130,7 @@ def time_dft_kernels(n, t, device, reps=3):
         sm = dft.mix(sa, wf, c)
         sdu = dft.transform(du, None, None, False, s, tin, 75)
         smb = dft.mix(sdu, wb, c)
-        fmix = 2.0 * 4 * c * c * 16 * nf * n
+        fmix = 2.0 * 3 * c * c * 16 * nf * n
         spec_bytes = 4.0 * sa.numel()
         stages = [
             ("dft_transform", lambda: dft.transform(y, sc, sh, True, 1, tin, 75), 1.0 * rows * tin * c * 16 * n, 4.0 * y.numel() + spec_bytes),
@@ -287,7 +287,7 @@ def model_flops_per_sequence_dft(t, kt=75, k=3):
         to = (tt - 1) // s + 1
         rows, nf, _ = dft.geometry(tt, kt)
         gcn = 2.0 * ci * k * co * tt * 16 + 2.0 * k * co * tt * 16 * 16 + (2.0 * ci * co * to * 16 if (ci != co or s != 1) else 0.0)
-        mixf = 2.0 * 4 * co * co * 16 * nf
+        mixf = 2.0 * 3 * co * co * 16 * nf
         f = 1.0 * rows * tt * co * 16 + mixf + 1.0 * rows * to * co * 16
         b = 1.0 * rows * to * co * 16 + mixf + 1.0 * rows * tt * co * 16 + mixf
         fwd += gcn + f

@@ -362,11 +362,14 @@ int step_tcn_wgrad_split(const float* dout, const float* in,
  * extents; the forward table is the cos half's tiling (NF rows, k < Kh) followed by the sin half's, the inverse table has
  * ceil(T_out / 2) rows and k < 2 NF (cos part against the real rows, sin part against the imaginary rows).  C % 8 == 0.
  *   step_dft_fwd   S = F . act(in)      in (N,C,K,16) [BN scale/shift + ReLU on the load]
- *   step_dft_mix   out[n][.][co][v] = W[f] . in[n][.][ci][v] per bin; wmat [NF][2 Ci][2 Co] from step_dft_wspec
+ *   step_dft_mix   out[n][.][co][v] = W[f] . in[n][.][ci][v] per bin, complex, as THREE real products (Gauss: k1 = (a+b) Xr,
+ *                  k2 = a (Xi - Xr), k3 = b (Xr + Xi); Re = k1 - k3, Im = k1 + k2); wmat = the triples (a+b, a, b, 0) per
+ *                  (row, k), [NF][rows / 32][K / 2][2][32][4] floats = NF * 4 * Co * Ci, from step_dft_wspec
  *   step_dft_inv   out (N,C,T_out,16) = G . S (+ bias); optional SUM out, SUM out^2 per channel (as step_tcn_conv_stats),
  *                  or step_tcn_conv's eval-mode epilogue (BN2 affine, residual with its affine, ReLU: classifier.py:189-191)
  *   step_dft_wspec taps (Co,Ci,Kt) [or the ConvTranspose2d layout] -> forward and backward mixing matrices
- *   step_dft_wgrad dw, db from the spectra of dout and of the activated input (kept from the forward pass)
+ *   step_dft_wgrad dw, db from the spectra of dout and of the activated input (kept from the forward pass); the per-bin
+ *                  complex products again as three real GEMMs
  *   step_dft_groups(T_out): partial-sum rows per sample that step_dft_inv's statistics use (step_dft_inv_ws_bytes)  */
 int step_dft_rows(int T, int Kt);
 int step_dft_table_geom(int rows, int inverse, int* mgp, int* groups);

@@ -10,7 +10,7 @@
 //
 //   r[co, tau] = SUM_ci SUM_j w[co,ci,j] a[ci, tau + j - P]      (P = (Kt-1)/2, a = 0 outside [0, T); u[t'] = r[s t'])
 //   a^[ci,f]   = SUM_t a[ci,t] e^{-2 pi i f t / L}                              step_dft_fwd   (matrix F, [2 NF x T])
-//   r^[co,f]   = SUM_ci w^[co,ci,f] a^[ci,f],  w^[f] = SUM_j w[j] e^{+2 pi i f (j-P)/L}   step_dft_mix   (per bin f)
+//   r^[co,f]   = SUM_ci w^[co,ci,f] a^[ci,f],  w^[f] = SUM_j w[j] e^{+2 pi i f (j-P)/L}   step_dft_mix   (per bin f; 3 real products)
 //   u[co,t']   = SUM_f kappa_f / L Re(r^[co,f] e^{+2 pi i f s t'/L}) + b[co]     step_dft_inv   (matrix G, [To x 2 NF])
 // L = 2 NF - 1 is odd (no Nyquist bin; kappa_0 = 1, kappa_f = 2), 2 NF = round_up(T + P + 1, 32); the circular
 // correlation equals the linear one on tau in [0, T) because L >= T + P.  Backward:
@@ -274,38 +274,41 @@ __global__ __launch_bounds__(256, 2) void dft_gemm_kernel(DgParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// Channel mixing per frequency bin: Out[n][rows(f)][co][v] = Wb[f] (2 Co x 2 Ci, real block form of the complex matrix)
-// times In[n][rows(f)][ci][v].  Block = (bin, slice of the batch): Wb[f] sits in LDS (k-major), a wave takes pairs of
-// samples (32 columns = 2 samples x 16 joints) and all row tiles - waves are autonomous, no barrier in the loop.
+// Channel mixing per frequency bin: R[f] = W[f] X[f], complex (rows x K) times (K x columns), with THREE real products
+// instead of four (Gauss): with W = a + i b per (row, k) and X = Xr + i Xi per (k, column)
+//   k1 = (a + b) Xr,   k2 = a (Xi - Xr),   k3 = b (Xr + Xi);     Re R = k1 - k3,   Im R = k1 + k2
+// The weights come as the triples (a + b, a, b, 0) per (row, k) (step_dft_wspec), the two operand combinations are two
+// VALU instructions per loaded pair: 25 % fewer MFMAs than the real block form [[a, -b], [b, a]] - this kernel runs
+// with its MFMA pipe ~80 % busy at a power-limited clock, so the multiply count is what its time follows.
+// Block = (bin, slice of the batch): the bin's triples sit in LDS ([row tile][k / 2][k % 2][32 rows][4]: a lane's three
+// A values for one k are one 16-byte read); a wave owns one tile of 32 output rows (both its real and its imaginary
+// result) and walks pairs of samples (32 columns = 2 samples x 16 joints) - no barrier in the loop.  All operand values
+// of a pair are requested at once, the next pair's while this one multiplies.
 struct MxParams {
     const float* in;
-    const float* wb;     // [NF][2 Ci][2 Co]
+    const float* wb;     // [NF][rows / 32][K / 2][2][32][4]
     float* out;
     int N, Ci, Co, NF;
 };
 
-// A wave owns ONE tile of 32 output rows and keeps its slice of Wb[f] in registers (CI values per lane: no LDS, no
-// barrier); the MT waves of a row of tiles walk the same pairs of samples (32 columns = 2 samples x 16 joints), their
-// operand loads meet in the L1.  All CI operand values of a pair are requested at once, the next pair's while this one
-// multiplies.
-template <int MT, int CI>        // row tiles = 2 Co / 32, input channels
+template <int CT, int CI>        // row tiles = Co / 32, input channels
 __global__ __launch_bounds__(256, 2) void dft_mix_kernel(MxParams p) {
+    extern __shared__ __attribute__((aligned(16))) float wl[];          // CT * CI * 128 floats
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, half = lane >> 5;
     const int npar = l31 >> 4, v = l31 & 15;
     const int f = blockIdx.x;
-    constexpr int K2 = 2 * CI;
-    constexpr int STREAMS = 4 / MT;                          // independent pair streams per block
-    const int mt = wave % MT, stream = wave / MT;
-    const int M2c = 2 * p.Co;
-    // A fragments: lane (half, row) holds W[row][k = 2 kk + half] for kk < CI
-    float wreg[CI];
+    constexpr int STREAMS = 4 / CT;                          // independent pair streams per block
+    constexpr int WTOT = CT * CI * 128;
+    const int ct = wave % CT, stream = wave / CT;
     {
-        const float* wsrc = p.wb + (size_t)f * K2 * M2c + (size_t)half * M2c + mt * 32 + l31;
-#pragma unroll
-        for (int kk = 0; kk < CI; ++kk) wreg[kk] = wsrc[(size_t)(2 * kk) * M2c];
+        const float* wsrc = p.wb + (size_t)f * WTOT;
+        for (int i = tid * 4; i < WTOT; i += 1024)
+            *reinterpret_cast<f32x4*>(&wl[i]) = *reinterpret_cast<const f32x4*>(wsrc + i);
     }
+    __syncthreads();
+    const float* wlane = wl + ((ct * (CI / 2)) * 2 + half) * 128 + l31 * 4;       // + kk * 256
     const int npairs = (p.N + 1) / 2;
     const int per = (npairs + gridDim.y - 1) / gridDim.y;
     const int p0 = blockIdx.y * per, p1 = min(npairs, p0 + per);
@@ -316,15 +319,15 @@ __global__ __launch_bounds__(256, 2) void dft_mix_kernel(MxParams p) {
     // k offsets - no per-access VALU work.
     const unsigned in_lane = (unsigned)(npar * in_sample + (f * CI + half) * 16 + v) * 4u;
     const unsigned part_jump = (unsigned)(p.NF * CI * 16) * 4u;
+    const unsigned im_jump = (unsigned)(p.NF * p.Co * 16) * 4u;
     unsigned out_lane[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const int m = mt * 32 + rowmap(r, half);
-        const int po = m >= p.Co ? 1 : 0, co = m - po * p.Co;
-        out_lane[r] = (unsigned)(npar * out_sample + ((size_t)(po * p.NF + f) * p.Co + co) * 16 + v) * 4u;
+        const int co = ct * 32 + rowmap(r, half);
+        out_lane[r] = (unsigned)(npar * out_sample + ((size_t)f * p.Co + co) * 16 + v) * 4u;
     }
 
-    float bc[CI], bn[CI];
+    float bc[CI], bn[CI];                                    // [0, CI/2): real rows (k = 2 ks + half), then imaginary rows
     auto load_pair = [&](int pr, float (&b)[CI]) {
         const int have = min(2, p.N - 2 * pr);
         const __amdgpu_buffer_rsrc_t rs = rsrc_n(p.in + (size_t)(2 * pr) * in_sample, (unsigned)(have * in_sample * 4));
@@ -338,15 +341,25 @@ __global__ __launch_bounds__(256, 2) void dft_mix_kernel(MxParams p) {
     if (pr < p1) load_pair(pr, bc);
     for (; pr < p1; pr += STREAMS) {
         if (pr + STREAMS < p1) load_pair(pr + STREAMS, bn);
-        f32x16 acc;
+        f32x16 k1, k2, k3;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        for (int r = 0; r < 16; ++r) { k1[r] = 0.f; k2[r] = 0.f; k3[r] = 0.f; }
 #pragma unroll
-        for (int kk = 0; kk < CI; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[kk], bc[kk], acc, 0, 0, 0);
+        for (int kk = 0; kk < CI / 2; ++kk) {
+            const f32x4 w = *reinterpret_cast<const f32x4*>(wlane + kk * 256);
+            const float xr = bc[kk], xi = bc[CI / 2 + kk];
+            k1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[0], xr, k1, 0, 0, 0);
+            k2 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[1], xi - xr, k2, 0, 0, 0);
+            k3 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[2], xr + xi, k3, 0, 0, 0);
+            if ((kk & 3) == 3) __builtin_amdgcn_sched_barrier(0);           // keep the LDS reads 4 k-steps ahead at most (registers)
+        }
         const int have = min(2, p.N - 2 * pr);
         const __amdgpu_buffer_rsrc_t ro = rsrc_n(p.out + (size_t)(2 * pr) * out_sample, (unsigned)(have * out_sample * 4));
 #pragma unroll
-        for (int r = 0; r < 16; ++r) bstore(ro, out_lane[r], 0u, acc[r]);
+        for (int r = 0; r < 16; ++r) {
+            bstore(ro, out_lane[r], 0u, k1[r] - k3[r]);
+            bstore(ro, out_lane[r] + im_jump, 0u, k1[r] + k2[r]);
+        }
         if (pr + STREAMS < p1) {
 #pragma unroll
             for (int kk = 0; kk < CI; ++kk) bc[kk] = bn[kk];
@@ -355,94 +368,79 @@ __global__ __launch_bounds__(256, 2) void dft_mix_kernel(MxParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// Weight gradient per bin: P[f][split][m][k'] = SUM_(n in split, v) dS[n][row(m)][co][v] * S[n][row(k')][ci][v]
-// (m over 2 Co: real | imaginary rows of du^, k' over 2 Ci of a^).  A lane loads the 8 joints 8 half .. 8 half + 7 of its
-// row as two float4; MFMA step e pairs joint e (k = 0) with joint 8 + e (k = 1) in BOTH operands.  Block = (bin, slice);
-// its 4 waves split the (2 Co / 32) x (2 Ci / 32) tiles 2 x 2.
+// Weight gradient per bin: C^[f] = SUM_(n, v) conj(D) A (D = du^, A = a^), the same three-product form:
+//   P1 = SUM (Dr - Di) Ar,   P2 = SUM Dr (Ai - Ar),   P3 = SUM Di (Ar + Ai);     Re C^ = P1 + P3,   Im C^ = P1 + P2
+// part[f][split][3][Co][Ci].  A lane loads the 8 joints 8 half .. 8 half + 7 of its row as two float4; MFMA step e pairs
+// joint e (k = 0) with joint 8 + e (k = 1) in BOTH operands.  Block = (bin, slice of the batch); wave (wm, wn) owns the
+// (co tile wm, ci tile wn) pair of 32 x 32 tiles.
 struct WgParams {
     const float* ds;     // du^  [N][2 NF][Co][16]
     const float* s;      // a^   [N][2 NF][Ci][16]
-    float* part;         // [NF][nsplit][2 Co][2 Ci]
+    float* part;         // [NF][nsplit][3][Co][Ci]
     int N, Ci, Co, NF, nsplit;
 };
 
-template <int TM, int TN>     // tiles per wave
-__global__ __launch_bounds__(256) void dft_wgrad_kernel(WgParams p) {
+template <int CT>             // tiles per side: Co / 32 = Ci / 32; block = CT * CT waves
+__global__ __launch_bounds__(64 * CT * CT) void dft_wgrad_kernel(WgParams p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, half = lane >> 5;
     const int f = blockIdx.x, split = blockIdx.y;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / CT, wn = wave % CT;
     const int n0 = (int)((long long)p.N * split / p.nsplit), n1 = (int)((long long)p.N * (split + 1) / p.nsplit);
     const size_t ds_sample = (size_t)2 * p.NF * p.Co * 16, s_sample = (size_t)2 * p.NF * p.Ci * 16;
-    unsigned aoff[TM], boff[TN];
+    // rows: real part at bin f, imaginary part NF rows further
+    const unsigned aoff = (unsigned)((f * p.Co + wm * 32 + l31) * 16 + 8 * half), ajump = (unsigned)(p.NF * p.Co * 16);
+    const unsigned boff = (unsigned)((f * p.Ci + wn * 32 + l31) * 16 + 8 * half), bjump = (unsigned)(p.NF * p.Ci * 16);
+    f32x16 acc[3];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int m = (wm * TM + i) * 32 + l31;
-        const int part = m >= p.Co ? 1 : 0, co = m - part * p.Co;
-        aoff[i] = (unsigned)(((part * p.NF + f) * p.Co + co) * 16 + 8 * half);
-    }
+    for (int i = 0; i < 3; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int k = (wn * TN + j) * 32 + l31;
-        const int part = k >= p.Ci ? 1 : 0, ci = k - part * p.Ci;
-        boff[j] = (unsigned)(((part * p.NF + f) * p.Ci + ci) * 16 + 8 * half);
-    }
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
-    f32x4 a[TM][2], b[TN][2], an[TM][2], bn[TN][2];
-    auto load = [&](int n, f32x4 (&x)[TM][2], f32x4 (&y)[TN][2]) {
-        const float* da = p.ds + (size_t)n * ds_sample;
-        const float* sb = p.s + (size_t)n * s_sample;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            x[i][0] = *reinterpret_cast<const f32x4*>(da + aoff[i]);
-            x[i][1] = *reinterpret_cast<const f32x4*>(da + aoff[i] + 4);
-        }
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            y[j][0] = *reinterpret_cast<const f32x4*>(sb + boff[j]);
-            y[j][1] = *reinterpret_cast<const f32x4*>(sb + boff[j] + 4);
-        }
+    f32x4 x[8], xn[8];                   // Dr (2), Di (2), Ar (2), Ai (2)
+    auto load = [&](int n, f32x4 (&y)[8]) {
+        const float* da = p.ds + (size_t)n * ds_sample + aoff;
+        const float* sb = p.s + (size_t)n * s_sample + boff;
+        y[0] = *reinterpret_cast<const f32x4*>(da);
+        y[1] = *reinterpret_cast<const f32x4*>(da + 4);
+        y[2] = *reinterpret_cast<const f32x4*>(da + ajump);
+        y[3] = *reinterpret_cast<const f32x4*>(da + ajump + 4);
+        y[4] = *reinterpret_cast<const f32x4*>(sb);
+        y[5] = *reinterpret_cast<const f32x4*>(sb + 4);
+        y[6] = *reinterpret_cast<const f32x4*>(sb + bjump);
+        y[7] = *reinterpret_cast<const f32x4*>(sb + bjump + 4);
     };
-    if (n0 < n1) load(n0, a, b);
+    if (n0 < n1) load(n0, x);
     for (int n = n0; n < n1; ++n) {
-        if (n + 1 < n1) load(n + 1, an, bn);
+        if (n + 1 < n1) load(n + 1, xn);
 #pragma unroll
-        for (int e = 0; e < 8; ++e)
+        for (int h = 0; h < 2; ++h) {
+            const f32x4 dr = x[h], di = x[2 + h], ar = x[4 + h], ai = x[6 + h];
+            const f32x4 dm = dr - di, bd = ai - ar, bs = ar + ai;
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e >> 2][e & 3], b[j][e >> 2][e & 3], acc[i][j], 0, 0, 0);
+            for (int e = 0; e < 4; ++e) {
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(dm[e], ar[e], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(dr[e], bd[e], acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(di[e], bs[e], acc[2], 0, 0, 0);
+            }
+        }
         if (n + 1 < n1) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) { a[i][0] = an[i][0]; a[i][1] = an[i][1]; }
-#pragma unroll
-            for (int j = 0; j < TN; ++j) { b[j][0] = bn[j][0]; b[j][1] = bn[j][1]; }
+            for (int i = 0; i < 8; ++i) x[i] = xn[i];
         }
     }
-    const int M2c = 2 * p.Co, K2 = 2 * p.Ci;
-    float* dst = p.part + ((size_t)f * p.nsplit + split) * M2c * K2;
+    float* dst = p.part + ((size_t)f * p.nsplit + split) * 3 * p.Co * p.Ci;
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < 3; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = (wm * TM + i) * 32 + rowmap(r, half);
-                const int k = (wn * TN + j) * 32 + l31;
-                dst[(size_t)m * K2 + k] = acc[i][j][r];
-            }
+        for (int r = 0; r < 16; ++r) {
+            const int co = wm * 32 + rowmap(r, half), ci = wn * 32 + l31;
+            dst[((size_t)i * p.Co + co) * p.Ci + ci] = acc[i][r];
+        }
 }
 
-// C^[f][co][ci] = kap_f / L * ordered sum over the batch slices of (Prr + Pii, Pri - Pir); then
+// C^[f][co][ci] = kap_f / L * ordered sum over the batch slices of (P1 + P3, P1 + P2); then
 // dw[co][ci][j] = SUM_f (C^r[f] tc[f][j] - C^i[f] ts[f][j]);  db[co] = SUM_(n,v) du^[n][0][co][v] in a fixed order.
 // tc / ts: [NF][Kt] cos / sin of 2 pi f (j - P) / L.
 __global__ __launch_bounds__(256) void dft_cfold_kernel(const float* __restrict__ part, float* __restrict__ chat, int Ci,
@@ -450,12 +448,13 @@ __global__ __launch_bounds__(256) void dft_cfold_kernel(const float* __restrict_
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= NF * Co * Ci) return;
     const int ci = e % Ci, co = (e / Ci) % Co, f = e / (Ci * Co);
-    const int K2 = 2 * Ci;
+    const size_t plane = (size_t)Co * Ci, o = (size_t)co * Ci + ci;
     float cr = 0.f, cim = 0.f;
     for (int s = 0; s < nsplit; ++s) {
-        const float* P = part + ((size_t)f * nsplit + s) * (2 * Co) * K2;
-        cr += P[(size_t)co * K2 + ci] + P[(size_t)(Co + co) * K2 + Ci + ci];
-        cim += P[(size_t)co * K2 + Ci + ci] - P[(size_t)(Co + co) * K2 + ci];
+        const float* P = part + ((size_t)f * nsplit + s) * 3 * plane;
+        const float p1 = P[o];
+        cr += p1 + P[2 * plane + o];
+        cim += p1 + P[plane + o];
     }
     const float kap = (f == 0 ? 1.f : 2.f) / (float)L;
     chat[(size_t)(2 * f) * Co * Ci + co * Ci + ci] = cr * kap;
@@ -511,9 +510,9 @@ __global__ __launch_bounds__(256) void dft_db_kernel(const float* __restrict__ d
     if (threadIdx.x == 0) db[co] = (float)red[0];
 }
 
-// w^[f] from the taps, as the two real block matrices the mixing kernel takes (k-major):
-//   forward  wf[f][k][m]: rows m = (part, co), columns k = (part, ci): [[Wr, -Wi], [Wi, Wr]]
-//   backward wb[f][k][m]: rows m = (part, ci), columns k = (part, co): [[Wr^T, Wi^T], [-Wi^T, Wr^T]]   (conj(w^)^T)
+// w^[f] from the taps, as the triples (a + b, a, b, 0) the mixing kernel takes, W[row][k] = a + i b:
+//   forward  wf[f][co / 32][ci / 2][ci % 2][co % 32][4]: a = Wr, b = Wi
+//   backward wb[f][ci / 32][co / 2][co % 2][ci % 32][4]: a = Wr, b = -Wi          (conj(w^)^T)
 __global__ __launch_bounds__(256) void dft_wspec_kernel(const float* __restrict__ w, const float* __restrict__ tc,
                                                         const float* __restrict__ ts, float* __restrict__ wf,
                                                         float* __restrict__ wb, int Ci, int Co, int NF, int Kt,
@@ -527,17 +526,13 @@ __global__ __launch_bounds__(256) void dft_wspec_kernel(const float* __restrict_
         wr += x * tc[(size_t)f * Kt + j];
         wi += x * ts[(size_t)f * Kt + j];
     }
-    const int Mf = 2 * Co, Mb = 2 * Ci;
-    float* F = wf + (size_t)f * (2 * Ci) * Mf;
-    F[(size_t)ci * Mf + co] = wr;
-    F[(size_t)(Ci + ci) * Mf + co] = -wi;
-    F[(size_t)ci * Mf + Co + co] = wi;
-    F[(size_t)(Ci + ci) * Mf + Co + co] = wr;
-    float* B = wb + (size_t)f * (2 * Co) * Mb;
-    B[(size_t)co * Mb + ci] = wr;
-    B[(size_t)(Co + co) * Mb + ci] = wi;
-    B[(size_t)co * Mb + Ci + ci] = -wi;
-    B[(size_t)(Co + co) * Mb + Ci + ci] = wr;
+    f32x4* F = reinterpret_cast<f32x4*>(wf) + ((((size_t)f * (Co / 32) + co / 32) * (Ci / 2) + ci / 2) * 2 + (ci & 1)) * 32 + (co & 31);
+    f32x4* B = reinterpret_cast<f32x4*>(wb) + ((((size_t)f * (Ci / 32) + ci / 32) * (Co / 2) + co / 2) * 2 + (co & 1)) * 32 + (ci & 31);
+    f32x4 tf, tb;
+    tf[0] = wr + wi; tf[1] = wr; tf[2] = wi; tf[3] = 0.f;
+    tb[0] = wr - wi; tb[1] = wr; tb[2] = -wi; tb[3] = 0.f;
+    *F = tf;
+    *B = tb;
 }
 
 int pick_mg(int mtiles, bool inverse) {
@@ -675,21 +670,34 @@ extern "C" int step_dft_mix(const float* in, const float* wmat, float* out, int 
     ny = ny < 1 ? 1 : ny;
     const dim3 grid((unsigned)NF, (unsigned)ny);
     hipStream_t st = (hipStream_t)stream;
-    if (Co == 64 && Ci == 64) hipLaunchKernelGGL((dft_mix_kernel<4, 64>), grid, dim3(256), 0, st, p);
-    else if (Co == 64) hipLaunchKernelGGL((dft_mix_kernel<4, 32>), grid, dim3(256), 0, st, p);
-    else if (Ci == 64) hipLaunchKernelGGL((dft_mix_kernel<2, 64>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((dft_mix_kernel<2, 32>), grid, dim3(256), 0, st, p);
+    const size_t lds = (size_t)Co * Ci * 16;                     // (Co / 32) * Ci * 128 floats: 64 KB at 64 x 64
+    hipError_t e = hipSuccess;
+#define MX_CASE(CTV, CIV)                                                                                              \
+    do {                                                                                                               \
+        auto kern = dft_mix_kernel<CTV, CIV>;                                                                          \
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (e == hipSuccess) hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);                                    \
+    } while (0)
+    if (Co == 64 && Ci == 64) MX_CASE(2, 64);
+    else if (Co == 64) MX_CASE(2, 32);
+    else if (Ci == 64) MX_CASE(1, 64);
+    else MX_CASE(1, 32);
+#undef MX_CASE
+    if (e != hipSuccess) {
+        step::set_error("step_dft_mix: hipFuncSetAttribute(%zu): %s", lds, hipGetErrorString(e));
+        return STEP_ERR_LAUNCH;
+    }
     return step::check_launch("step_dft_mix");
 }
 
-static int wgrad_nsplit(int N, int NF) {
-    int ns = step::ceil_div(768, NF);
+static int wgrad_nsplit(int N, int NF, int C) {
+    int ns = step::ceil_div(C == 32 ? 3072 : 768, NF);           // (32 channels: one wave per block)
     ns = ns > N ? N : ns;
     return ns < 1 ? 1 : ns;
 }
 extern "C" size_t step_dft_wgrad_ws_bytes(int N, int Ci, int Co, int NF) {
     if (N < 1 || Ci < 1 || Co < 1 || NF < 1) return 0;
-    return ((size_t)NF * wgrad_nsplit(N, NF) * 4 * Ci * Co + (size_t)NF * 2 * Ci * Co) * sizeof(float);
+    return ((size_t)NF * wgrad_nsplit(N, NF, Co) * 3 * Ci * Co + (size_t)NF * 2 * Ci * Co) * sizeof(float);
 }
 
 extern "C" int step_dft_wgrad(const float* dspec, const float* spec, const float* tc, const float* ts, float* dw,
@@ -703,13 +711,13 @@ extern "C" int step_dft_wgrad(const float* dspec, const float* spec, const float
         return STEP_ERR_WORKSPACE;
     }
     hipStream_t st = (hipStream_t)stream;
-    WgParams p{dspec, spec, (float*)ws, N, Ci, Co, NF, wgrad_nsplit(N, NF)};
+    WgParams p{dspec, spec, (float*)ws, N, Ci, Co, NF, wgrad_nsplit(N, NF, Co)};
     const dim3 grid((unsigned)NF, (unsigned)p.nsplit);
-    if (Co == 64) hipLaunchKernelGGL((dft_wgrad_kernel<2, 2>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((dft_wgrad_kernel<1, 1>), grid, dim3(256), 0, st, p);
+    if (Co == 64) hipLaunchKernelGGL((dft_wgrad_kernel<2>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((dft_wgrad_kernel<1>), grid, dim3(64), 0, st, p);
     int rc = step::check_launch("step_dft_wgrad");
     if (rc != STEP_OK) return rc;
-    float* chat = (float*)ws + (size_t)NF * p.nsplit * 4 * Ci * Co;
+    float* chat = (float*)ws + (size_t)NF * p.nsplit * 3 * Ci * Co;
     hipLaunchKernelGGL(dft_cfold_kernel, dim3(step::ceil_div(NF * Co * Ci, 256)), dim3(256), 0, st, (const float*)ws, chat,
                        Ci, Co, NF, p.nsplit, 2 * NF - 1);
     rc = step::check_launch("step_dft_wgrad(fold)");

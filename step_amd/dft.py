@@ -112,7 +112,7 @@ def tap_tables(T, Kt, T_out, stride, device):
 
 
 def weight_spectrum(w, C, T, Kt, transposed, T_out=None, stride=1):
-    """(forward, backward) mixing matrices [NF][2C][2C] of the taps w (Co,Ci,Kt,1) [or (Ci,Co,Kt,1) when transposed]
+    """(forward, backward) mixing weights (NF * 4 C^2 floats each: the triples of csrc/tcn_dft.hip) of the taps w (Co,Ci,Kt,1) [or (Ci,Co,Kt,1) when transposed]
     for a conv from T frames to T_out frames at `stride`"""
     rows, NF, L = geometry(T, Kt)
     tc, ts = tap_tables(T, Kt, T if T_out is None else T_out, stride, w.device)

@@ -55,12 +55,12 @@ def main():
     stages = [
         ("wspec", lambda: dft.weight_spectrum(w, c, t, kt, False, to, s), 0),
         ("fwd: transform(a)", lambda: dft.transform(y, sc, sh, True, 1, t, kt), 1.0 * rows * t * c * 16 * n),
-        ("fwd: mix", lambda: dft.mix(sa, wf, c), 2.0 * 4 * c * c * 16 * NF * n),
+        ("fwd: mix", lambda: dft.mix(sa, wf, c), 2.0 * 3 * c * c * 16 * NF * n),
         ("fwd: inverse(+stats)", lambda: dft.inverse(sm, b, to, s, t, kt, sums), 1.0 * rows * to * c * 16 * n),
         ("bwd: transform(du)", lambda: dft.transform(du, None, None, False, s, t, kt), 1.0 * rows * to * c * 16 * n),
-        ("bwd: mix", lambda: dft.mix(sdu, wb, c), 2.0 * 4 * c * c * 16 * NF * n),
+        ("bwd: mix", lambda: dft.mix(sdu, wb, c), 2.0 * 3 * c * c * 16 * NF * n),
         ("bwd: inverse", lambda: dft.inverse(smb, None, t, 1, t, kt), 1.0 * rows * t * c * 16 * n),
-        ("bwd: wgrad", lambda: dft.conv_wgrad(sdu, sa, t, kt, False, tuple(w.shape), to, s), 2.0 * 4 * c * c * 16 * NF * n),
+        ("bwd: wgrad", lambda: dft.conv_wgrad(sdu, sa, t, kt, False, tuple(w.shape), to, s), 2.0 * 3 * c * c * 16 * NF * n),
     ]
     tot = {"fwd": 0.0, "bwd": 0.0}
     print("C=%d s=%d T=%d N=%d Kt=%d: rows=%d L=%d, spectrum %.2f GB" % (c, s, t, n, kt, rows, L, n * rows * c * 64 / 1e9))
