@@ -3,10 +3,12 @@
 // Same operator as step_tcn_conv / step_tcn_wgrad (tcn[2] of st_gcn / st_gctn, classifier_stgcn_real_only/net/
 // classifier.py:156-162, generator_cvae/net/CVAE_stgcn.py:359-365, and both gradients).  A 75-tap correlation along t
 // costs 75 multiply-adds per output, input and output channel; with the frames of a (sample, channel, joint) row taken
-// to L >= T + (Kt-1)/2 frequency bins the channel mixing costs 4 real multiply-adds per BIN, and the two transforms are
-// themselves small dense GEMMs against fixed cos / sin matrices (a "DFT by matmul": any T, no butterflies, exact zero
-// padding, strides and ConvTranspose are just other matrices).  For 64 channels, T = 240, stride 2 that is 4.2x fewer
-// multiply-adds than the direct kernels execute (10x at T = 120, stride 1), all of them still fp32 MFMA work.
+// to L >= T + (Kt-1)/2 frequency bins the channel mixing costs 3 real multiply-adds per BIN (a complex product as three
+// real ones), and the two transforms are themselves small dense GEMMs against fixed cos / sin matrices (a "DFT by
+// matmul": any T, no butterflies, exact zero padding, strides and ConvTranspose are just other matrices) of HALF the
+// dense size: the frames are paired about their centre, the cos rows act on the pair sums, the sin rows on the pair
+// differences.  For 64 channels, T = 240, stride 2 that is 7x fewer multiply-adds than the direct kernels execute
+// (14x at T = 120, stride 1), all of them still fp32 MFMA work.
 //
 //   r[co, tau] = SUM_ci SUM_j w[co,ci,j] a[ci, tau + j - P]      (P = (Kt-1)/2, a = 0 outside [0, T); u[t'] = r[s t'])
 //   a^[ci,f]   = SUM_t a[ci,t] e^{-2 pi i f t / L}                              step_dft_fwd   (matrix F, [2 NF x T])
