@@ -357,10 +357,11 @@ __global__ __launch_bounds__(256, 2) void dft_mix_kernel(MxParams p) {
         }
         const int have = min(2, p.N - 2 * pr);
         const __amdgpu_buffer_rsrc_t ro = rsrc_n(p.out + (size_t)(2 * pr) * out_sample, (unsigned)(have * out_sample * 4));
+        const f32x16 re = k1 - k3, im = k1 + k2;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            bstore(ro, out_lane[r], 0u, k1[r] - k3[r]);
-            bstore(ro, out_lane[r] + im_jump, 0u, k1[r] + k2[r]);
+            bstore(ro, out_lane[r], 0u, re[r]);
+            bstore(ro, out_lane[r], im_jump, im[r]);          // (the uniform jump in the SGPR offset: the pair's descriptor covers it)
         }
         if (pr + STREAMS < p1) {
 #pragma unroll
@@ -383,7 +384,7 @@ struct WgParams {
 };
 
 template <int CT>             // tiles per side: Co / 32 = Ci / 32; block = CT * CT waves
-__global__ __launch_bounds__(64 * CT * CT) void dft_wgrad_kernel(WgParams p) {
+__global__ __launch_bounds__(64 * CT * CT) __attribute__((amdgpu_num_vgpr(128))) void dft_wgrad_kernel(WgParams p) {      // 4 waves per SIMD
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, half = lane >> 5;
@@ -413,12 +414,13 @@ __global__ __launch_bounds__(64 * CT * CT) void dft_wgrad_kernel(WgParams p) {
         y[6] = *reinterpret_cast<const f32x4*>(sb + bjump);
         y[7] = *reinterpret_cast<const f32x4*>(sb + bjump + 4);
     };
-    if (n0 < n1) load(n0, x);
-    for (int n = n0; n < n1; ++n) {
-        if (n + 1 < n1) load(n + 1, xn);
+    // (the two operand sets swap roles from sample to sample: no register copies in the MFMA stream - every
+    // instruction of a SIMD's waves costs its MFMA stream the issue time)
+    auto do_sample = [&](int n, const f32x4 (&cur)[8], f32x4 (&nxt)[8]) {
+        if (n + 1 < n1) load(n + 1, nxt);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const f32x4 dr = x[h], di = x[2 + h], ar = x[4 + h], ai = x[6 + h];
+            const f32x4 dr = cur[h], di = cur[2 + h], ar = cur[4 + h], ai = cur[6 + h];
             const f32x4 dm = dr - di, bd = ai - ar, bs = ar + ai;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -427,10 +429,11 @@ __global__ __launch_bounds__(64 * CT * CT) void dft_wgrad_kernel(WgParams p) {
                 acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(di[e], bs[e], acc[2], 0, 0, 0);
             }
         }
-        if (n + 1 < n1) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) x[i] = xn[i];
-        }
+    };
+    if (n0 < n1) load(n0, x);
+    for (int n = n0; n < n1; n += 2) {
+        do_sample(n, x, xn);
+        if (n + 1 < n1) do_sample(n + 1, xn, x);
     }
     float* dst = p.part + ((size_t)f * p.nsplit + split) * 3 * p.Co * p.Ci;
 #pragma unroll
