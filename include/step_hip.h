@@ -383,6 +383,21 @@ int step_dft_inv(const float* spec, const float* matt, const float* bias,
                  const float* res, const float* res_scale, const float* res_shift, int out_relu,
                  float* out, int N, int C, int rows_in, int T_out,
                  double* sums, void* ws, size_t ws_bytes, void* stream);
+/* Long sequences at stride 1, overlap-save (no counterpart in the reference: the same tcn[2] conv, classifier.py:156-162,
+ * evaluated segment by segment so that the transforms cost S * K^2 instead of T^2): the row of T frames is cut into S
+ * segments of seg_step output frames; segment s transforms the K input frames starting at frame0 + s * seg_step (frame0 =
+ * -(Kt-1)/2; frames outside [0, T) are the conv's zero padding, applied after the activation) and writes its T_seg output
+ * frames at s * seg_step (frames past T_out are dropped).  Spectra are [N * S][rows][C][16] with rows = step_dft_rows(K -
+ * (Kt-1)/2, Kt) >= K + 1: the outputs kept never wrap.  step_dft_mix takes N * S samples; the tap tables carry the
+ * segment's origin shift (step_amd/dft.py).  ws for sums: S * step_dft_inv_ws_bytes(N, C, T_seg).                  */
+int step_dft_fwd_seg(const float* in, const float* in_scale, const float* in_shift, int in_relu,
+                     const float* matt, float* spec, int N, int C, int T, int K, int rows, int S, int seg_step,
+                     int frame0, void* stream);
+int step_dft_inv_seg(const float* spec, const float* matt, const float* bias,
+                     const float* out_scale, const float* out_shift,
+                     const float* res, const float* res_scale, const float* res_shift, int out_relu,
+                     float* out, int N, int C, int rows_in, int T_seg, int T_out, int S, int seg_step,
+                     double* sums, void* ws, size_t ws_bytes, void* stream);
 int step_dft_wspec(const float* w, const float* tc, const float* ts, float* wf, float* wb, int Ci, int Co,
                    int NF, int Kt, int transposed, void* stream);
 size_t step_dft_wgrad_ws_bytes(int N, int Ci, int Co, int NF);

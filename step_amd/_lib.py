@@ -51,6 +51,8 @@ SIGNATURES = {
     "step_dft_rows": (I, [I, I]),
     "step_dft_table_geom": (I, [I, I, P, P]),
     "step_dft_groups": (I, [I]),
+    "step_dft_fwd_seg": (I, [P, P, P, I, P, P, I, I, I, I, I, I, I, I, P]),
+    "step_dft_inv_seg": (I, [P, P, P, P, P, P, P, P, I, P, I, I, I, I, I, I, I, P, P, Z, P]),
     "step_dft_fwd": (I, [P, P, P, I, P, P, I, I, I, I, P]),
     "step_dft_mix": (I, [P, P, P, I, I, I, I, P]),
     "step_dft_inv_ws_bytes": (Z, [I, I, I]),

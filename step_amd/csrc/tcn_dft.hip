@@ -71,6 +71,11 @@ struct DgParams {
     float* out;
     double* stat_part;       // INV == 1: [N * groups][C][2] partial SUM out, SUM out^2, or null
     int in_relu;
+    // Segments (long sequences, stride 1: overlap-save): block z = sample * S + segment.  INV == 0 reads the K frames
+    // frame0 + segment * seg_step + [0, K) of a channel row of Tfull frames (frames outside [0, Tfull) are the conv's zero
+    // padding: masked AFTER the activation); INV == 1 writes its Mrows frames at segment * seg_step of a row of Tfull
+    // frames (frames past the row's end are dropped).  One segment: S = 1, seg_step = frame0 = 0, Tfull = K / Mrows.
+    int S, seg_step, frame0, Tfull;
     int N, C, K, Kpad, Mpad, Mrows;   // INV == 0: K frames, Kpad = round_up(ceil(K/2), KC), Mrows = 2 NF; INV == 1: K = Kpad = 2 NF, Mrows = T_out
 };
 
@@ -96,22 +101,26 @@ __global__ __launch_bounds__(256, 2) void dft_gemm_kernel(DgParams p) {
     const int m0 = g * MGR;                             // first row of the group within its half / first pair
     const int nchunk = p.Kpad / KC;
 
-    const int n = blockIdx.z;
+    const int nz = blockIdx.z;                          // sample * S + segment: the spectrum's "sample"
+    const int n = nz / p.S, seg = nz - n * p.S;
     const int c = blockIdx.y * 8 + wave * 2 + cpar;
 
     // B operand addressing: descriptor on the sample, lane offsets, uniform k offsets
-    const size_t sample = (size_t)p.C * p.K * 16;
-    const __amdgpu_buffer_rsrc_t rs = rsrc_n(p.in + (size_t)n * sample, (unsigned)(sample * 4));
+    const size_t sample = INV ? (size_t)p.C * p.K * 16 : (size_t)p.C * p.Tfull * 16;
+    const __amdgpu_buffer_rsrc_t rs = rsrc_n(p.in + (size_t)(INV ? nz : n) * sample, (unsigned)(sample * 4));
     const int Kh = (p.K + 1) >> 1;                      // INV == 0: pairs of frames
+    const int mf = p.frame0 + seg * p.seg_step;         // INV == 0: the window's first frame in the row (may be negative)
     const unsigned kstride = INV ? (unsigned)p.C * 64u : 64u;                       // bytes per k
     const unsigned voff = INV ? (unsigned)c * 64u + half * kstride + v * 4u
-                              : ((unsigned)c * (unsigned)p.K + (unsigned)(Kh + half)) * 64u + v * 4u;      // frame hi of pair `half`
-    const unsigned voff_lo = ((unsigned)c * (unsigned)p.K + (unsigned)(Kh - 1 - half)) * 64u + v * 4u;      // frame lo
+                              : (unsigned)((c * p.Tfull + mf + Kh + half) * 64 + v * 4);                  // frame hi of pair `half`
+    const unsigned voff_lo = (unsigned)((c * p.Tfull + mf + Kh - 1 - half) * 64 + v * 4);                  // frame lo
     float sc = 1.f, sh = 0.f;
     const bool act = !INV && p.in_scale != nullptr;
     if (act) { sc = p.in_scale[c]; sh = p.in_shift[c]; }
     const float lo = (!INV && p.in_relu) ? 0.f : -__builtin_inff();
-    const int nhi = p.K - Kh;                           // pairs whose hi frame exists (K odd: one fewer than Kh)
+    // pairs (k + half) whose hi / lo frame exists: inside the window (K odd: one hi fewer) and inside the row
+    const int hi_lo = max(0, -(mf + Kh)), hi_n = max(0, min(p.K - Kh, p.Tfull - mf - Kh) - hi_lo);
+    const int lo_lo = max(0, mf + Kh - p.Tfull), lo_n = max(0, min(Kh, mf + Kh) - lo_lo);
 
     f32x16 acc[NACC];
 #pragma unroll
@@ -148,8 +157,8 @@ __global__ __launch_bounds__(256, 2) void dft_gemm_kernel(DgParams p) {
                 float xl = bload(rs, voff_lo - (unsigned)k * 64u, 0u);
                 if (act) { xh = xh * sc + sh; xl = xl * sc + sh; }
                 xh = fmaxf(xh, lo); xl = fmaxf(xl, lo);
-                xh = (k + half < nhi) ? xh : 0.f;                             // the odd frame out / k padding (the matrix is 0 there too)
-                xl = (k + half < Kh) ? xl : 0.f;
+                xh = ((unsigned)(k + half - hi_lo) < (unsigned)hi_n) ? xh : 0.f;    // the odd frame out / k padding (the matrix is 0 there
+                xl = ((unsigned)(k + half - lo_lo) < (unsigned)lo_n) ? xl : 0.f;    // too) / the conv's zero padding outside the row
                 b[ks] = xh + xl;
                 b[KC / 2 + ks] = xh - xl;
             }
@@ -211,7 +220,7 @@ __global__ __launch_bounds__(256, 2) void dft_gemm_kernel(DgParams p) {
         const unsigned ol = ((unsigned)(m0 + 4 * half) * (unsigned)p.C * 16u + (unsigned)c * 16u + v) * 4u;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const __amdgpu_buffer_rsrc_t ro = rsrc_n(p.out + (size_t)n * osample, (unsigned)((size_t)(h + 1) * NF * p.C * 64));
+            const __amdgpu_buffer_rsrc_t ro = rsrc_n(p.out + (size_t)nz * osample, (unsigned)((size_t)(h + 1) * NF * p.C * 64));
             const unsigned oh = ol + (unsigned)(h * NF) * rowb;
 #pragma unroll
             for (int i = 0; i < MG; ++i)
@@ -228,13 +237,15 @@ __global__ __launch_bounds__(256, 2) void dft_gemm_kernel(DgParams p) {
         // descriptor on the sample; pair j -> frames Th + j and Th - 1 - j of the lane's channel row, both masked
         // (padding pairs of the last tile, the odd frame out)
         const int Th = (p.Mrows + 1) >> 1;
-        const size_t osample = (size_t)p.C * p.Mrows * 16;
+        const size_t osample = (size_t)p.C * p.Tfull * 16;
+        const int fo = seg * p.seg_step;                    // the segment's first frame in the output row
         const __amdgpu_buffer_rsrc_t ro = rsrc_n(p.out + (size_t)n * osample, (unsigned)(osample * 4));
         const __amdgpu_buffer_rsrc_t rr = rsrc_n(p.res ? p.res + (size_t)n * osample : p.out, p.res ? (unsigned)(osample * 4) : 0u);
         const int j0 = m0 + 4 * half;
-        const unsigned ol_hi = ((unsigned)c * (unsigned)p.Mrows * 16u + (unsigned)(Th + j0) * 16u + v) * 4u;
-        const unsigned ol_lo = ((unsigned)c * (unsigned)p.Mrows * 16u + (unsigned)(Th - 1 - j0) * 16u + v) * 4u;
-        const int nlo = Th - j0, nhi_o = p.Mrows - Th - j0;          // pairs (relative to the lane's first) whose lo / hi frame exists
+        const unsigned ol_hi = (unsigned)(((c * p.Tfull + fo + Th + j0) * 16 + v) * 4);
+        const unsigned ol_lo = (unsigned)(((c * p.Tfull + fo + Th - 1 - j0) * 16 + v) * 4);
+        // pairs (relative to the lane's first) whose lo / hi frame exists - in the segment and in the row
+        const int nlo = Th - j0, nhi_o = min(p.Mrows, p.Tfull - fo) - Th - j0, nlo_min = fo + Th - j0 - p.Tfull;
         float s1 = 0.f, s2 = 0.f;
         auto finish = [&](float x, unsigned off) {
             x += bia;
@@ -253,7 +264,7 @@ __global__ __launch_bounds__(256, 2) void dft_gemm_kernel(DgParams p) {
                 const int mr = i * 32 + (r & 3) + 8 * (r >> 2);
                 const float e = acc[i][r], o = acc[MG + i][r];
                 if (mr < nhi_o) finish(e + o, ol_hi + (unsigned)mr * 64u);
-                if (mr < nlo) finish(e - o, ol_lo - (unsigned)mr * 64u);
+                if (mr < nlo && mr >= nlo_min) finish(e - o, ol_lo - (unsigned)mr * 64u);
             }
         if (p.stat_part) {
             // per (block, channel): the 16 joints by DPP row rotations, the two halves by a shuffle; fp64 from here on
@@ -268,7 +279,7 @@ __global__ __launch_bounds__(256, 2) void dft_gemm_kernel(DgParams p) {
             a1 += __shfl_xor(a1, 32, 64);
             a2 += __shfl_xor(a2, 32, 64);
             if (half == 0 && v == 0) {
-                double* d = p.stat_part + (((size_t)n * gridDim.x + g) * p.C + c) * 2;
+                double* d = p.stat_part + (((size_t)nz * gridDim.x + g) * p.C + c) * 2;
                 d[0] = (double)a1; d[1] = (double)a2;
             }
         }
@@ -563,7 +574,7 @@ int launch_gemm(DgParams p, hipStream_t st, const char* what) {
     const int mtiles = p.Mpad / 32;
     const int mg = pick_mg(mtiles, INV);
     const int groups = step::ceil_div(mtiles, mg);
-    const dim3 grid((unsigned)groups, (unsigned)(p.C / 8), (unsigned)p.N);
+    const dim3 grid((unsigned)groups, (unsigned)(p.C / 8), (unsigned)(p.N * p.S));
 #define DG_CASE(MGV) case MGV: hipLaunchKernelGGL((dft_gemm_kernel<MGV, INV>), grid, dim3(256), 0, st, p); return step::check_launch(what)
     if constexpr (INV) {
         switch (mg) { DG_CASE(2); DG_CASE(3); DG_CASE(4); default: break; }
@@ -606,27 +617,43 @@ extern "C" int step_dft_groups(int T_out) {
     return step::ceil_div(mtiles, pick_mg(mtiles, true));
 }
 
-extern "C" int step_dft_fwd(const float* in, const float* in_scale, const float* in_shift, int in_relu,
-                            const float* matt, float* spec, int N, int C, int K, int rows, void* stream) {
+// Long sequences at stride 1 (overlap-save): the row of T frames is cut into S segments of seg_step output frames;
+// segment s transforms the K = seg_step + Kt - 1 input frames [s * seg_step - P, s * seg_step + seg_step + P) (frames
+// outside [0, T) are the conv's zero padding), and its circular product needs no more than L >= K bins because the
+// outputs kept never wrap - the transforms cost S * K^2 instead of T^2.  The spectra are [N * S][rows][C][16];
+// step_dft_mix / step_dft_wspec take them as N * S samples (tap tables with the segment's origin shift, dft.py).
+extern "C" int step_dft_fwd_seg(const float* in, const float* in_scale, const float* in_shift, int in_relu,
+                                const float* matt, float* spec, int N, int C, int T, int K, int rows, int S, int seg_step,
+                                int frame0, void* stream) {
     STEP_REQUIRE(in && matt && spec, "step_dft_fwd: null pointer");
-    STEP_REQUIRE(N >= 1 && N <= 65535 && C >= 8 && C % 8 == 0 && C / 8 <= 65535 && K >= 1 && rows >= 32 && rows % 32 == 0,
-                 "step_dft_fwd: bad shape N=%d C=%d K=%d rows=%d", N, C, K, rows);
+    STEP_REQUIRE(N >= 1 && S >= 1 && (long long)N * S <= 65535 && C >= 8 && C % 8 == 0 && C / 8 <= 65535 && K >= 1 && T >= 1 &&
+                 rows >= 32 && rows % 32 == 0 && seg_step >= 0,
+                 "step_dft_fwd: bad shape N=%d C=%d T=%d K=%d rows=%d S=%d", N, C, T, K, rows, S);
     STEP_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "step_dft_fwd: scale/shift pair");
-    STEP_REQUIRE((size_t)C * K * 64 < (1ull << 31) && (size_t)rows * C * 64 < (1ull << 31), "step_dft_fwd: sample too large");
+    STEP_REQUIRE(((size_t)C * T + K + (size_t)S * seg_step + 64) * 64 < (1ull << 31) && (size_t)rows * C * 64 < (1ull << 31),
+                 "step_dft_fwd: sample too large");
     DgParams p{};
     p.in = in; p.matt = matt; p.in_scale = in_scale; p.in_shift = in_shift; p.in_relu = in_relu; p.out = spec;
     p.N = N; p.C = C; p.K = K; p.Kpad = step::round_up((K + 1) / 2, KC); p.Mpad = step::round_up(rows / 2, 32); p.Mrows = rows;
+    p.S = S; p.seg_step = seg_step; p.frame0 = frame0; p.Tfull = T;
     return launch_gemm<false>(p, (hipStream_t)stream, "step_dft_fwd");
 }
 
-extern "C" int step_dft_inv(const float* spec, const float* matt, const float* bias, const float* out_scale,
-                            const float* out_shift, const float* res, const float* res_scale, const float* res_shift,
-                            int out_relu, float* out, int N, int C, int rows_in, int T_out, double* sums, void* ws,
-                            size_t ws_bytes, void* stream) {
+extern "C" int step_dft_fwd(const float* in, const float* in_scale, const float* in_shift, int in_relu,
+                            const float* matt, float* spec, int N, int C, int K, int rows, void* stream) {
+    return step_dft_fwd_seg(in, in_scale, in_shift, in_relu, matt, spec, N, C, K, K, rows, 1, 0, 0, stream);
+}
+
+extern "C" int step_dft_inv_seg(const float* spec, const float* matt, const float* bias, const float* out_scale,
+                                const float* out_shift, const float* res, const float* res_scale, const float* res_shift,
+                                int out_relu, float* out, int N, int C, int rows_in, int T_seg, int T_out, int S,
+                                int seg_step, double* sums, void* ws, size_t ws_bytes, void* stream) {
     STEP_REQUIRE(spec && matt && out, "step_dft_inv: null pointer");
-    STEP_REQUIRE(N >= 1 && N <= 65535 && C >= 8 && C % 8 == 0 && C / 8 <= 65535 && T_out >= 1 && rows_in >= 32 && rows_in % 32 == 0,
-                 "step_dft_inv: bad shape N=%d C=%d rows=%d T=%d", N, C, rows_in, T_out);
-    STEP_REQUIRE((size_t)C * T_out * 64 < (1ull << 31) && (size_t)rows_in * C * 64 < (1ull << 31), "step_dft_inv: sample too large");
+    STEP_REQUIRE(N >= 1 && S >= 1 && (long long)N * S <= 65535 && C >= 8 && C % 8 == 0 && C / 8 <= 65535 && T_out >= 1 &&
+                 T_seg >= 1 && rows_in >= 32 && rows_in % 32 == 0 && seg_step >= 0,
+                 "step_dft_inv: bad shape N=%d C=%d rows=%d T=%d (%d x %d)", N, C, rows_in, T_out, S, T_seg);
+    STEP_REQUIRE(((size_t)C * T_out + T_seg + (size_t)S * seg_step + 64) * 64 < (1ull << 31) && (size_t)rows_in * C * 64 < (1ull << 31),
+                 "step_dft_inv: sample too large");
     DgParams p{};
     STEP_REQUIRE((out_scale == nullptr) == (out_shift == nullptr) && (res_scale == nullptr) == (res_shift == nullptr),
                  "step_dft_inv: scale/shift must come in pairs");
@@ -634,10 +661,11 @@ extern "C" int step_dft_inv(const float* spec, const float* matt, const float* b
     p.in = spec; p.matt = matt; p.bias = bias; p.out = out;
     p.out_scale = out_scale; p.out_shift = out_shift; p.res = res; p.res_scale = res_scale; p.res_shift = res_shift;
     p.out_relu = out_relu;
-    p.N = N; p.C = C; p.K = rows_in; p.Kpad = rows_in; p.Mpad = step::round_up((T_out + 1) / 2, 32); p.Mrows = T_out;
-    const int groups = step_dft_groups(T_out);
+    p.N = N; p.C = C; p.K = rows_in; p.Kpad = rows_in; p.Mpad = step::round_up((T_seg + 1) / 2, 32); p.Mrows = T_seg;
+    p.S = S; p.seg_step = seg_step; p.frame0 = 0; p.Tfull = T_out;
+    const int groups = step_dft_groups(T_seg);
     if (sums) {
-        const size_t need = (size_t)N * groups * C * 2 * sizeof(double);
+        const size_t need = (size_t)N * S * groups * C * 2 * sizeof(double);
         if (!ws || ws_bytes < need) {
             step::set_error("step_dft_inv: workspace %zu < %zu bytes", ws_bytes, need);
             return STEP_ERR_WORKSPACE;
@@ -646,7 +674,15 @@ extern "C" int step_dft_inv(const float* spec, const float* matt, const float* b
     }
     const int rc = launch_gemm<true>(p, (hipStream_t)stream, "step_dft_inv");
     if (rc != STEP_OK || !sums) return rc;
-    return step::bn_sum_partials((const double*)ws, sums, C, N * groups, (hipStream_t)stream);
+    return step::bn_sum_partials((const double*)ws, sums, C, N * S * groups, (hipStream_t)stream);
+}
+
+extern "C" int step_dft_inv(const float* spec, const float* matt, const float* bias, const float* out_scale,
+                            const float* out_shift, const float* res, const float* res_scale, const float* res_shift,
+                            int out_relu, float* out, int N, int C, int rows_in, int T_out, double* sums, void* ws,
+                            size_t ws_bytes, void* stream) {
+    return step_dft_inv_seg(spec, matt, bias, out_scale, out_shift, res, res_scale, res_shift, out_relu, out, N, C, rows_in,
+                            T_out, T_out, 1, 0, sums, ws, ws_bytes, stream);
 }
 
 extern "C" size_t step_dft_inv_ws_bytes(int N, int C, int T_out) {

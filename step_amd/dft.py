@@ -98,10 +98,12 @@ def inv_matrix(T_out, step, T, Kt, device):
     return _TABLES[key]
 
 
-def tap_tables(T, Kt, T_out, stride, device):
+def tap_tables(T, Kt, T_out, stride, device, d2=None):
     """tc / ts [NF][Kt]: cos / sin of 2 pi f (j - P + delta) / L; delta = the output's time origin minus the input's
-    (0 at stride 1, -1/2 at stride 2 with even T): the phase between the two spectra lives in the weights"""
-    d2 = centre2(T_out, stride) - centre2(T, 1)
+    (0 at stride 1, -1/2 at stride 2 with even T): the phase between the two spectra lives in the weights.  d2 = 2 delta
+    may be given (segments: the outputs sit P frames into the input window)"""
+    if d2 is None:
+        d2 = centre2(T_out, stride) - centre2(T, 1)
     key = ("taps", T, Kt, d2, str(device))
     if key not in _TABLES:
         rows, NF, L = geometry(T, Kt)
@@ -177,3 +179,61 @@ def conv_wgrad(sdu, sa, T, Kt, transposed, wshape, T_out=None, stride=1):
     ws = torch.empty(nb, dtype=torch.uint8, device=sa.device)
     _lib.call("step_dft_wgrad", sdu, sa, tc, ts, dw, db, N, C, C, rows // 2, Kt, int(transposed), ws, nb)
     return dw, db
+
+
+# ------------------------------------------------------------------ long sequences: overlap-save (eval forward)
+SEGMENT = 256
+
+
+def seg_plan(C, T, T_out, stride, Kt):
+    """(S, seg, K, Tv, stride) when the eval forward of a conv over T frames is cheaper in S segments of `seg` input
+    frames = seg / stride output frames (each a transform of K = seg + Kt - 1 input frames with L >= K bins: S K^2
+    instead of T^2), else None.  Cost = multiply-adds + 20 x bytes (the two roofs' ratio: these kernels pay for both,
+    DESIGN 4.6); taken under 80 % of the whole-row form - T = 1024 (configs[4]) yes, T <= 512 no.  Tv = K - P is the
+    sequence length whose geometry (step_dft_rows) gives the segment's L."""
+    if stride not in (1, 2) or T_out != (T - 1) // stride + 1 or not supported(C, Kt) or T < 2 * SEGMENT:
+        return None
+    P = (Kt - 1) // 2
+    seg = SEGMENT
+    S = (T + seg - 1) // seg
+    K = seg + Kt - 1
+    Tv = K - P
+    rows_w = _lib.query("step_dft_rows", T, Kt)
+    rows_s = _lib.query("step_dft_rows", Tv, Kt)
+
+    def cost(rows, frames_in, frames_out, nseg):
+        flops = nseg * (rows * (frames_in + frames_out) * C * 16 + 6.0 * C * C * 16 * (rows // 2))
+        nbytes = (4.0 * nseg * rows + T + T_out) * C * 64
+        return flops + 20.0 * nbytes
+    if cost(rows_s, K, seg // stride, S) < 0.8 * cost(rows_w, T, T_out, 1):
+        return S, seg, K, Tv, stride
+    return None
+
+
+def weight_spectrum_seg(w, C, Kt, transposed, plan):
+    """forward mixing weights for the segments of `plan`: the outputs of a segment sit P frames into its input window"""
+    S, seg, K, Tv, stride = plan
+    rows, NF, L = geometry(Tv, Kt)
+    d2 = (Kt - 1) + centre2(seg // stride, stride) - centre2(K, 1)
+    tc, ts = tap_tables(Tv, Kt, seg // stride, stride, w.device, d2)
+    wf = torch.empty(NF * 4 * C * C, dtype=torch.float32, device=w.device)
+    wb = torch.empty_like(wf)
+    _lib.call("step_dft_wspec", w, tc, ts, wf, wb, C, C, NF, Kt, int(transposed))
+    return wf
+
+
+def conv_forward_seg(y, scale, shift, relu, wf, bias, Kt, plan, epilogue=None):
+    """u = conv(act(y)) + bias (+ the eval-mode tail), segment by segment; wf from weight_spectrum_seg"""
+    N, C, T, V = y.shape
+    S, seg, K, Tv, stride = plan
+    T_out = (T - 1) // stride + 1
+    rows, NF, L = geometry(Tv, Kt)
+    spec = torch.empty((N * S, rows, C, 16), dtype=torch.float32, device=y.device)
+    _lib.call("step_dft_fwd_seg", y, scale, shift, int(relu), fwd_matrix(K, 1, Tv, Kt, y.device), spec, N, C, T, K, rows,
+              S, seg, -((Kt - 1) // 2))
+    spec = mix(spec, wf, C)
+    out = torch.empty((N, C, T_out, 16), dtype=torch.float32, device=y.device)
+    osc, osh, res, rsc, rsh, orelu = epilogue if epilogue is not None else (None, None, None, None, None, False)
+    _lib.call("step_dft_inv_seg", spec, inv_matrix(seg // stride, stride, Tv, Kt, y.device), bias, osc, osh, res, rsc, rsh,
+              int(orelu), out, N, C, rows, seg // stride, T_out, S, seg // stride, None, None, 0)
+    return out

@@ -512,6 +512,13 @@ class StGcnBlockFn(torch.autograd.Function):
             res_t = x
         if s.dft == "force" or (s.dft == "auto" and _dft_mod.preferred(Co, Kt, T, To)):
             # frequency domain: the weights' spectrum is cached per parameter version and sequence length
+            plan = _dft_mod.seg_plan(Co, T, To, st, Kt)
+            if plan is not None:
+                # long sequence: overlap-save, the transforms cost S K^2 instead of T^2 (dft.seg_plan)
+                wf_seg = cached(c, "wf_dft_seg", tensor_key(tcn_w) + plan + (int(s.transposed),),
+                                lambda: _dft_mod.weight_spectrum_seg(tcn_w, Co, Kt, s.transposed, plan))
+                return _dft_mod.conv_forward_seg(y, s1, h1, True, wf_seg, tcn_b, Kt, plan,
+                                                 epilogue=(s2, h2, res_t, sr, hr, True))
             wf_dft = cached(c, "wf_dft", tensor_key(tcn_w) + (T, To, st, int(s.transposed)),
                             lambda: _dft_mod.weight_spectrum(tcn_w, Co, T, Kt, s.transposed, To, st)[0])
             out, _ = _dft_mod.conv_forward(y, s1, h1, True, wf_dft, tcn_b, To, st, Kt,

@@ -50,3 +50,37 @@ def test_dft_conv_forward_dgrad_wgrad_vs_oracle(C, stride, T, N, tr, Kt):
     # no statistics asked, no activation: the plain paths
     u2, _ = dft.conv_forward(yd, None, None, False, wf, None, To, stride, Kt)
     assert_close(u2, stgcn.temporal_conv(y.double(), w.double(), None, stride, tr), 1e-4, "u, plain")
+
+
+@pytest.mark.parametrize("C,T,N,tr,Kt,stride", [(64, 1024, 2, False, 75, 1), (32, 700, 3, False, 75, 1), (64, 530, 2, True, 75, 1),
+                                                 (32, 300, 2, False, 9, 1), (64, 1024, 2, False, 75, 2), (64, 701, 2, False, 75, 2)])
+def test_dft_segmented_eval_forward_vs_oracle(C, T, N, tr, Kt, stride):
+    """overlap-save form of the forward (long sequences: step_dft_fwd_seg / _inv_seg), strides 1 and 2, with the last
+    segment partial, ConvTranspose taps and the eval-mode tail (BN2 affine, residual with its affine, ReLU)"""
+    from step_amd import dft
+    g = torch.Generator().manual_seed(C + T + N + Kt + stride)
+    To = (T - 1) // stride + 1
+    y = torch.randn(N, C, T, 16, generator=g)
+    w = torch.randn(C, C, Kt, 1, generator=g) * 0.05
+    b = torch.randn(C, generator=g)
+    sc, sh = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3
+    res = torch.randn(N, C, To, 16, generator=g)
+    osc, osh = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3
+    rsc, rsh = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3
+    v = lambda t: t.double().view(1, -1, 1, 1)
+    a64 = torch.relu(y.double() * v(sc) + v(sh))
+    u64 = stgcn.temporal_conv(a64, w.double(), b.double(), stride, tr)
+    seg = 256 if Kt == 75 else 128
+    S = (T + seg - 1) // seg
+    K = seg + Kt - 1
+    plan = (S, seg, K, K - (Kt - 1) // 2, stride)
+    if T == 1024:
+        assert dft.seg_plan(C, T, To, stride, Kt) == plan          # what the model takes at configs[4]'s length
+    yd, wd, bd, scd, shd = (t.to(D) for t in (y, w, b, sc, sh))
+    wf = dft.weight_spectrum_seg(wd, C, Kt, tr, plan)
+    u = dft.conv_forward_seg(yd, scd, shd, True, wf, bd, Kt, plan)
+    assert_close(u, u64, 1e-4, "u, segmented")
+    out64 = torch.relu(u64 * v(osc) + v(osh) + res.double() * v(rsc) + v(rsh))
+    out = dft.conv_forward_seg(yd, scd, shd, True, wf, bd, Kt, plan,
+                               epilogue=tuple(t.to(D) for t in (osc, osh, res, rsc, rsh)) + (True,))
+    assert_close(out, out64, 1e-4, "eval tail, segmented")
