@@ -185,7 +185,7 @@ def conv_wgrad(sdu, sa, T, Kt, transposed, wshape, T_out=None, stride=1):
 SEGMENT = 256
 
 
-def seg_plan(C, T, T_out, stride, Kt):
+def seg_plan(C, T, T_out, stride, Kt, N=1):
     """(S, seg, K, Tv, stride) when the eval forward of a conv over T frames is cheaper in S segments of `seg` input
     frames = seg / stride output frames (each a transform of K = seg + Kt - 1 input frames with L >= K bins: S K^2
     instead of T^2), else None.  Cost = multiply-adds + 20 x bytes (the two roofs' ratio: these kernels pay for both,
@@ -196,6 +196,8 @@ def seg_plan(C, T, T_out, stride, Kt):
     P = (Kt - 1) // 2
     seg = SEGMENT
     S = (T + seg - 1) // seg
+    if N * S > 65535:                       # (the segment index rides in the grid's z dimension with the sample)
+        return None
     K = seg + Kt - 1
     Tv = K - P
     rows_w = _lib.query("step_dft_rows", T, Kt)

@@ -512,7 +512,7 @@ class StGcnBlockFn(torch.autograd.Function):
             res_t = x
         if s.dft == "force" or (s.dft == "auto" and _dft_mod.preferred(Co, Kt, T, To)):
             # frequency domain: the weights' spectrum is cached per parameter version and sequence length
-            plan = _dft_mod.seg_plan(Co, T, To, st, Kt)
+            plan = _dft_mod.seg_plan(Co, T, To, st, Kt, N)
             if plan is not None:
                 # long sequence: overlap-save, the transforms cost S K^2 instead of T^2 (dft.seg_plan)
                 wf_seg = cached(c, "wf_dft_seg", tensor_key(tcn_w) + plan + (int(s.transposed),),
