@@ -147,6 +147,24 @@ __global__ __launch_bounds__(256, 2) void dft_gemm_kernel(DgParams p) {
     constexpr int NB = INV ? KC / 2 : KC;              // INV == 0: pair sums, then pair differences
     float bcur[NB], bnxt[NB];
     auto load_b = [&](int kc, float (&b)[NB]) {
+        if constexpr (!INV) {
+            // a chunk whose 16 pairs all have both frames (every chunk but the last, and the first of a segment at the
+            // row's start) needs no masks: 64 VALU instructions fewer beside the MFMA stream (uniform branch)
+            const int k0 = kc * KC;
+            if (k0 >= hi_lo && k0 + KC <= hi_lo + hi_n && k0 >= lo_lo && k0 + KC <= lo_lo + lo_n) {
+#pragma unroll
+                for (int ks = 0; ks < KC / 2; ++ks) {
+                    const int k = k0 + 2 * ks;
+                    float xh = bload(rs, voff + (unsigned)k * 64u, 0u);
+                    float xl = bload(rs, voff_lo - (unsigned)k * 64u, 0u);
+                    if (act) { xh = xh * sc + sh; xl = xl * sc + sh; }
+                    xh = fmaxf(xh, lo); xl = fmaxf(xl, lo);
+                    b[ks] = xh + xl;
+                    b[KC / 2 + ks] = xh - xl;
+                }
+                return;
+            }
+        }
 #pragma unroll
         for (int ks = 0; ks < KC / 2; ++ks) {
             const int k = kc * KC + 2 * ks;                                  // (+ half: in the lane offsets)
