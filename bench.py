@@ -118,7 +118,11 @@ def time_dft_kernels(n, t, device, reps=3):
     g = torch.Generator().manual_seed(11)
     for bi, (c, s, tin) in enumerate([(32, 1, t), (64, 2, t), (64, 1, (t - 1) // 2 + 1)]):
         tout = (tin - 1) // s + 1
-        rows, nf, L = dft.geometry(tin, 75)
+        # stride 2 runs as two stride-1 convs on the even / odd frames (dft.phases): transforms of tin / 2 frames on a
+        # grid of ~half the bins, 2 C -> C mixing per bin
+        ph = dft.phases(c, tin, 75, s, False)
+        tg, ktg = dft.phase_geometry(tin, 75) if ph == 2 else (tin, 75)
+        rows, nf, L = dft.geometry(tg, ktg)
         y = torch.randn(n, c, tin, 16, generator=g).to(device)
         du = torch.randn(n, c, tout, 16, generator=g).to(device)
         w = (torch.randn(c, c, 75, 1, generator=g) * 0.02).to(device)
@@ -126,20 +130,33 @@ def time_dft_kernels(n, t, device, reps=3):
         sc, sh = torch.ones(c, device=device), torch.zeros(c, device=device)
         wf, wb = dft.weight_spectrum(w, c, tin, 75, False, tout, s)
         sums = torch.zeros(2 * c + 1, dtype=torch.float64, device=device)
-        sa = dft.transform(y, sc, sh, True, 1, tin, 75)
-        sm = dft.mix(sa, wf, c)
-        sdu = dft.transform(du, None, None, False, s, tin, 75)
-        smb = dft.mix(sdu, wb, c)
-        fmix = 2.0 * 3 * c * c * 16 * nf * n
-        spec_bytes = 4.0 * sa.numel()
+        if ph == 2:
+            tr_a = lambda: dft.transform_phases(y, sc, sh, True, tin, 75)
+            mix_f = lambda: dft.mix(sa, wf, 2 * c, c)
+            inv_f = lambda: dft.inverse(sm, b, tout, 1, tg, ktg, sums)
+            mix_b = lambda: dft.mix(sdu, wb, c, 2 * c)
+            da = torch.empty_like(y)
+            inv_b = lambda: dft._lib.call("step_dft_inv_ph", smb, dft.inv_matrix(tg, 1, tg, ktg, device), da, n, c, rows, tg, 2)
+        else:
+            tr_a = lambda: dft.transform(y, sc, sh, True, 1, tin, 75)
+            mix_f = lambda: dft.mix(sa, wf, c)
+            inv_f = lambda: dft.inverse(sm, b, tout, s, tin, 75, sums)
+            mix_b = lambda: dft.mix(sdu, wb, c)
+            inv_b = lambda: dft.inverse(smb, None, tin, 1, tin, 75)
+        sa = tr_a()
+        sm = mix_f()
+        sdu = dft.transform_dout(du, s, tin, 75)
+        smb = mix_b()
+        fmix = 2.0 * 3 * c * c * ph * 16 * nf * n
+        sa_bytes, sdu_bytes = 4.0 * sa.numel(), 4.0 * sdu.numel()      # (sa holds both phases: ph * C channels)
         stages = [
-            ("dft_transform", lambda: dft.transform(y, sc, sh, True, 1, tin, 75), 1.0 * rows * tin * c * 16 * n, 4.0 * y.numel() + spec_bytes),
-            ("dft_mix", lambda: dft.mix(sa, wf, c), fmix, 2 * spec_bytes),
-            ("dft_inverse", lambda: dft.inverse(sm, b, tout, s, tin, 75, sums), 1.0 * rows * tout * c * 16 * n, spec_bytes + 4.0 * du.numel()),
-            ("dft_transform_dout", lambda: dft.transform(du, None, None, False, s, tin, 75), 1.0 * rows * tout * c * 16 * n, 4.0 * du.numel() + spec_bytes),
-            ("dft_mix_bwd", lambda: dft.mix(sdu, wb, c), fmix, 2 * spec_bytes),
-            ("dft_inverse_bwd", lambda: dft.inverse(smb, None, tin, 1, tin, 75), 1.0 * rows * tin * c * 16 * n, spec_bytes + 4.0 * y.numel()),
-            ("dft_wgrad", lambda: dft.conv_wgrad(sdu, sa, tin, 75, False, tuple(w.shape), tout, s), fmix, 2 * spec_bytes),
+            ("dft_transform", tr_a, 1.0 * rows * tin * c * 16 * n, 4.0 * y.numel() + sa_bytes),
+            ("dft_mix", mix_f, fmix, sa_bytes + sdu_bytes),
+            ("dft_inverse", inv_f, 1.0 * rows * tout * c * 16 * n, sdu_bytes + 4.0 * du.numel()),
+            ("dft_transform_dout", lambda: dft.transform_dout(du, s, tin, 75), 1.0 * rows * tout * c * 16 * n, 4.0 * du.numel() + sdu_bytes),
+            ("dft_mix_bwd", mix_b, fmix, sdu_bytes + sa_bytes),
+            ("dft_inverse_bwd", inv_b, 1.0 * rows * tin * c * 16 * n, sa_bytes + 4.0 * y.numel()),
+            ("dft_wgrad", lambda: dft.conv_wgrad(sdu, sa, tin, 75, False, tuple(w.shape), tout, s), fmix, sa_bytes + sdu_bytes),
         ]
         for name, fn, fl, nbytes in stages:
             fn()
@@ -151,7 +168,7 @@ def time_dft_kernels(n, t, device, reps=3):
             e1.record()
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / reps
-            out.append({"kernel": "%s_b%d" % (name, bi), "C": c, "stride": s, "T_in": tin, "rows": rows, "ms": round(ms, 3),
+            out.append({"kernel": "%s_b%d" % (name, bi), "C": c, "stride": s, "T_in": tin, "rows": rows, "phases": ph, "ms": round(ms, 3),
                         "tflops": round(fl / ms / 1e9, 2), "frac": round(fl / ms / 1e9 / PEAK_FP32_MFMA_TFLOPS, 4),
                         "flops_per_launch": fl, "gbs": round(nbytes / ms / 1e6, 1),
                         "frac_hbm": round(nbytes / ms / 1e6 / PEAK_HBM_GBS, 4)})
@@ -285,9 +302,10 @@ def model_flops_per_sequence_dft(t, kt=75, k=3):
     fwd, both, ci, tt = 0.0, 0.0, 3, t
     for co, s in ((32, 1), (64, 2), (64, 1)):
         to = (tt - 1) // s + 1
-        rows, nf, _ = dft.geometry(tt, kt)
+        ph = dft.phases(co, tt, kt, s, False)          # stride 2: two stride-1 convs on the even / odd frames
+        rows, nf, _ = dft.geometry(*dft.phase_geometry(tt, kt)) if ph == 2 else dft.geometry(tt, kt)
         gcn = 2.0 * ci * k * co * tt * 16 + 2.0 * k * co * tt * 16 * 16 + (2.0 * ci * co * to * 16 if (ci != co or s != 1) else 0.0)
-        mixf = 2.0 * 3 * co * co * 16 * nf
+        mixf = 2.0 * 3 * co * co * ph * 16 * nf
         f = 1.0 * rows * tt * co * 16 + mixf + 1.0 * rows * to * co * 16
         b = 1.0 * rows * to * co * 16 + mixf + 1.0 * rows * tt * co * 16 + mixf
         fwd += gcn + f

@@ -398,6 +398,19 @@ int step_dft_inv_seg(const float* spec, const float* matt, const float* bias,
                      const float* res, const float* res_scale, const float* res_shift, int out_relu,
                      float* out, int N, int C, int rows_in, int T_seg, int T_out, int S, int seg_step,
                      double* sums, void* ws, size_t ws_bytes, void* stream);
+/* A stride-2 conv as two stride-1 convs (polyphase; the same tcn[2] statement of a block with stride 2, classifier.py:156-162
+ * and the blocks of classifier.py:40-51): output frame t' reads the frames 2 t' + j - P, i.e. the even frames through the
+ * odd taps and the odd frames through the even taps.  The tensor (N, C, 2 Tp, 16) is taken as `phases` = 2 interleaved
+ * sequences of Tp frames per channel row; step_dft_fwd_ph writes the spectrum of sequence (c, ph) as channel 2 c + ph of
+ * spec [N][rows][phases * C][16] with rows = step_dft_rows(Tp, 2 ceil(P / 2) + 1) - every transform of the path works on
+ * Tp frames and ~half the bins.  step_dft_mix then mixes 2 C -> C channels per bin forward (C -> 2 C backward, wmat from
+ * step_dft_wspec on the taps split by phase, (Co, 2 ci + ph, Kt) with zeros where a tap belongs to the other phase, and a tap
+ * table whose column j holds the tap's offset within its phase), step_dft_inv gives the Tp output frames, step_dft_wgrad
+ * takes Ci = 2 Co, and step_dft_inv_ph returns the input gradient's two phases to their interleaved frames.           */
+int step_dft_fwd_ph(const float* in, const float* in_scale, const float* in_shift, int in_relu,
+                    const float* matt, float* spec, int N, int C, int Tp, int rows, int phases, void* stream);
+int step_dft_inv_ph(const float* spec, const float* matt, float* out, int N, int C, int rows_in, int Tp,
+                    int phases, void* stream);
 int step_dft_wspec(const float* w, const float* tc, const float* ts, float* wf, float* wb, int Ci, int Co,
                    int NF, int Kt, int transposed, void* stream);
 size_t step_dft_wgrad_ws_bytes(int N, int Ci, int Co, int NF);

@@ -54,6 +54,8 @@ SIGNATURES = {
     "step_dft_fwd_seg": (I, [P, P, P, I, P, P, I, I, I, I, I, I, I, I, P]),
     "step_dft_inv_seg": (I, [P, P, P, P, P, P, P, P, I, P, I, I, I, I, I, I, I, P, P, Z, P]),
     "step_dft_fwd": (I, [P, P, P, I, P, P, I, I, I, I, P]),
+    "step_dft_fwd_ph": (I, [P, P, P, I, P, P, I, I, I, I, I, P]),
+    "step_dft_inv_ph": (I, [P, P, P, I, I, I, I, I, P]),
     "step_dft_mix": (I, [P, P, P, I, I, I, I, P]),
     "step_dft_inv_ws_bytes": (Z, [I, I, I]),
     "step_dft_inv": (I, [P, P, P, P, P, P, P, P, I, P, I, I, I, I, P, P, Z, P]),

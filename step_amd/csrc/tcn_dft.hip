@@ -76,6 +76,11 @@ struct DgParams {
     // padding: masked AFTER the activation); INV == 1 writes its Mrows frames at segment * seg_step of a row of Tfull
     // frames (frames past the row's end are dropped).  One segment: S = 1, seg_step = frame0 = 0, Tfull = K / Mrows.
     int S, seg_step, frame0, Tfull;
+    // Phases (a stride-2 conv as two stride-1 convs on the even and the odd frames, step_amd/dft.py): the tensor holds
+    // fs = 2 interleaved sequences of Tfull frames per channel row; the spectrum has fs * C channels, channel fs * c + ph
+    // for phase ph of channel c (a wave's 2 x 16 lanes then touch 128 contiguous bytes of the tensor: frames 2 t and
+    // 2 t + 1 of one channel), every one an ordinary spectrum of its Tfull frames.  fs = 1: one sequence per row.
+    int fs;
     int N, C, K, Kpad, Mpad, Mrows;   // INV == 0: K frames, Kpad = round_up(ceil(K/2), KC), Mrows = 2 NF; INV == 1: K = Kpad = 2 NF, Mrows = T_out
 };
 
@@ -103,17 +108,20 @@ __global__ __launch_bounds__(256, 2) void dft_gemm_kernel(DgParams p) {
 
     const int nz = blockIdx.z;                          // sample * S + segment: the spectrum's "sample"
     const int n = nz / p.S, seg = nz - n * p.S;
-    const int c = blockIdx.y * 8 + wave * 2 + cpar;
+    const int cp = blockIdx.y * 8 + wave * 2 + cpar;    // channel of the spectrum = fs * channel of the tensor + phase
+    const int c = cp >> (p.fs - 1), ph = cp & (p.fs - 1);                   // fs is 1 or 2
+    const int CP = p.C * p.fs;
+    const unsigned fb = 64u * (unsigned)p.fs;           // bytes from a frame of a phase to its next
 
     // B operand addressing: descriptor on the sample, lane offsets, uniform k offsets
-    const size_t sample = INV ? (size_t)p.C * p.K * 16 : (size_t)p.C * p.Tfull * 16;
+    const size_t sample = INV ? (size_t)CP * p.K * 16 : (size_t)CP * p.Tfull * 16;
     const __amdgpu_buffer_rsrc_t rs = rsrc_n(p.in + (size_t)(INV ? nz : n) * sample, (unsigned)(sample * 4));
     const int Kh = (p.K + 1) >> 1;                      // INV == 0: pairs of frames
     const int mf = p.frame0 + seg * p.seg_step;         // INV == 0: the window's first frame in the row (may be negative)
-    const unsigned kstride = INV ? (unsigned)p.C * 64u : 64u;                       // bytes per k
-    const unsigned voff = INV ? (unsigned)c * 64u + half * kstride + v * 4u
-                              : (unsigned)((c * p.Tfull + mf + Kh + half) * 64 + v * 4);                  // frame hi of pair `half`
-    const unsigned voff_lo = (unsigned)((c * p.Tfull + mf + Kh - 1 - half) * 64 + v * 4);                  // frame lo
+    const unsigned kstride = INV ? (unsigned)CP * 64u : fb;                         // bytes per k
+    const unsigned voff = INV ? (unsigned)cp * 64u + half * kstride + v * 4u
+                              : (unsigned)(((c * p.Tfull + mf + Kh + half) * p.fs + ph) * 64 + v * 4);     // frame hi of pair `half`
+    const unsigned voff_lo = (unsigned)(((c * p.Tfull + mf + Kh - 1 - half) * p.fs + ph) * 64 + v * 4);     // frame lo
     float sc = 1.f, sh = 0.f;
     const bool act = !INV && p.in_scale != nullptr;
     if (act) { sc = p.in_scale[c]; sh = p.in_shift[c]; }
@@ -155,8 +163,8 @@ __global__ __launch_bounds__(256, 2) void dft_gemm_kernel(DgParams p) {
 #pragma unroll
                 for (int ks = 0; ks < KC / 2; ++ks) {
                     const int k = k0 + 2 * ks;
-                    float xh = bload(rs, voff + (unsigned)k * 64u, 0u);
-                    float xl = bload(rs, voff_lo - (unsigned)k * 64u, 0u);
+                    float xh = bload(rs, voff + (unsigned)k * fb, 0u);
+                    float xl = bload(rs, voff_lo - (unsigned)k * fb, 0u);
                     if (act) { xh = xh * sc + sh; xl = xl * sc + sh; }
                     xh = fmaxf(xh, lo); xl = fmaxf(xl, lo);
                     b[ks] = xh + xl;
@@ -171,8 +179,8 @@ __global__ __launch_bounds__(256, 2) void dft_gemm_kernel(DgParams p) {
             if constexpr (INV) {
                 b[ks] = bload(rs, voff, (unsigned)k * kstride);
             } else {
-                float xh = bload(rs, voff + (unsigned)k * 64u, 0u);     // (offsets in the VGPR: the range check sees all of them)
-                float xl = bload(rs, voff_lo - (unsigned)k * 64u, 0u);
+                float xh = bload(rs, voff + (unsigned)k * fb, 0u);      // (offsets in the VGPR: the range check sees all of them)
+                float xl = bload(rs, voff_lo - (unsigned)k * fb, 0u);
                 if (act) { xh = xh * sc + sh; xl = xl * sc + sh; }
                 xh = fmaxf(xh, lo); xl = fmaxf(xl, lo);
                 xh = ((unsigned)(k + half - hi_lo) < (unsigned)hi_n) ? xh : 0.f;    // the odd frame out / k padding (the matrix is 0 there
@@ -233,12 +241,12 @@ __global__ __launch_bounds__(256, 2) void dft_gemm_kernel(DgParams p) {
         // ends with its NF rows (NF is not a multiple of 32: its padding rows must not land in the sin half), the sin
         // half's with the sample
         const int NF = p.Mrows >> 1;
-        const size_t osample = (size_t)p.Mrows * p.C * 16;
-        const unsigned rowb = (unsigned)p.C * 64u;
-        const unsigned ol = ((unsigned)(m0 + 4 * half) * (unsigned)p.C * 16u + (unsigned)c * 16u + v) * 4u;
+        const size_t osample = (size_t)p.Mrows * CP * 16;
+        const unsigned rowb = (unsigned)CP * 64u;
+        const unsigned ol = ((unsigned)(m0 + 4 * half) * (unsigned)CP * 16u + (unsigned)cp * 16u + v) * 4u;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const __amdgpu_buffer_rsrc_t ro = rsrc_n(p.out + (size_t)nz * osample, (unsigned)((size_t)(h + 1) * NF * p.C * 64));
+            const __amdgpu_buffer_rsrc_t ro = rsrc_n(p.out + (size_t)nz * osample, (unsigned)((size_t)(h + 1) * NF * CP * 64));
             const unsigned oh = ol + (unsigned)(h * NF) * rowb;
 #pragma unroll
             for (int i = 0; i < MG; ++i)
@@ -255,13 +263,13 @@ __global__ __launch_bounds__(256, 2) void dft_gemm_kernel(DgParams p) {
         // descriptor on the sample; pair j -> frames Th + j and Th - 1 - j of the lane's channel row, both masked
         // (padding pairs of the last tile, the odd frame out)
         const int Th = (p.Mrows + 1) >> 1;
-        const size_t osample = (size_t)p.C * p.Tfull * 16;
+        const size_t osample = (size_t)CP * p.Tfull * 16;
         const int fo = seg * p.seg_step;                    // the segment's first frame in the output row
         const __amdgpu_buffer_rsrc_t ro = rsrc_n(p.out + (size_t)n * osample, (unsigned)(osample * 4));
         const __amdgpu_buffer_rsrc_t rr = rsrc_n(p.res ? p.res + (size_t)n * osample : p.out, p.res ? (unsigned)(osample * 4) : 0u);
         const int j0 = m0 + 4 * half;
-        const unsigned ol_hi = (unsigned)(((c * p.Tfull + fo + Th + j0) * 16 + v) * 4);
-        const unsigned ol_lo = (unsigned)(((c * p.Tfull + fo + Th - 1 - j0) * 16 + v) * 4);
+        const unsigned ol_hi = (unsigned)((((c * p.Tfull + fo + Th + j0) * p.fs + ph) * 16 + v) * 4);
+        const unsigned ol_lo = (unsigned)((((c * p.Tfull + fo + Th - 1 - j0) * p.fs + ph) * 16 + v) * 4);
         // pairs (relative to the lane's first) whose lo / hi frame exists - in the segment and in the row
         const int nlo = Th - j0, nhi_o = min(p.Mrows, p.Tfull - fo) - Th - j0, nlo_min = fo + Th - j0 - p.Tfull;
         float s1 = 0.f, s2 = 0.f;
@@ -281,8 +289,8 @@ __global__ __launch_bounds__(256, 2) void dft_gemm_kernel(DgParams p) {
             for (int r = 0; r < 16; ++r) {
                 const int mr = i * 32 + (r & 3) + 8 * (r >> 2);
                 const float e = acc[i][r], o = acc[MG + i][r];
-                if (mr < nhi_o) finish(e + o, ol_hi + (unsigned)mr * 64u);
-                if (mr < nlo && mr >= nlo_min) finish(e - o, ol_lo - (unsigned)mr * 64u);
+                if (mr < nhi_o) finish(e + o, ol_hi + (unsigned)mr * fb);
+                if (mr < nlo && mr >= nlo_min) finish(e - o, ol_lo - (unsigned)mr * fb);
             }
         if (p.stat_part) {
             // per (block, channel): the 16 joints by DPP row rotations, the two halves by a shuffle; fp64 from here on
@@ -322,20 +330,29 @@ struct MxParams {
     int N, Ci, Co, NF;
 };
 
+// Rectangular bins (the two phases of a stride-2 conv, step_amd/dft.py: 64 x 128 forward, 128 x 64 backward) hold 128 KB
+// of triples: one block of 8 waves per CU instead of two of 4; K = 128 goes through the registers in two halves (the
+// second half of a pair is requested while the first multiplies, the next pair's first half while the second does).
+constexpr int mix_waves(int CT, int CI) { return CT * CI > 128 ? 8 : 4; }
+
 template <int CT, int CI>        // row tiles = Co / 32, input channels
-__global__ __launch_bounds__(256, 2) void dft_mix_kernel(MxParams p) {
+__global__ __launch_bounds__(64 * mix_waves(CT, CI), 8 / mix_waves(CT, CI)) void dft_mix_kernel(MxParams p) {
     extern __shared__ __attribute__((aligned(16))) float wl[];          // CT * CI * 128 floats
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, half = lane >> 5;
     const int npar = l31 >> 4, v = l31 & 15;
     const int f = blockIdx.x;
-    constexpr int STREAMS = 4 / CT;                          // independent pair streams per block
+    constexpr int WAVES = mix_waves(CT, CI);
+    constexpr int STREAMS = WAVES / CT;                      // independent pair streams per block
     constexpr int WTOT = CT * CI * 128;
+    constexpr int KH = CI > 64 ? CI / 64 : 1;                // K in halves of 64
+    constexpr int CIH = CI / KH;
+    static_assert(KH == 1 || KH == 2, "K = 128 at most");
     const int ct = wave % CT, stream = wave / CT;
     {
         const float* wsrc = p.wb + (size_t)f * WTOT;
-        for (int i = tid * 4; i < WTOT; i += 1024)
+        for (int i = tid * 4; i < WTOT; i += WAVES * 256)
             *reinterpret_cast<f32x4*>(&wl[i]) = *reinterpret_cast<const f32x4*>(wsrc + i);
     }
     __syncthreads();
@@ -358,31 +375,42 @@ __global__ __launch_bounds__(256, 2) void dft_mix_kernel(MxParams p) {
         out_lane[r] = (unsigned)(npar * out_sample + ((size_t)f * p.Co + co) * 16 + v) * 4u;
     }
 
-    float bc[CI], bn[CI];                                    // [0, CI/2): real rows (k = 2 ks + half), then imaginary rows
-    auto load_pair = [&](int pr, float (&b)[CI]) {
+    float bc[CIH], bn[CIH];                                  // [0, CIH/2): real rows (k = 2 ks + half), then imaginary rows
+    auto load_pair = [&](int pr, int h, float (&b)[CIH]) {   // K half h: channels h * CIH + [0, CIH)
         const int have = min(2, p.N - 2 * pr);
         const __amdgpu_buffer_rsrc_t rs = rsrc_n(p.in + (size_t)(2 * pr) * in_sample, (unsigned)(have * in_sample * 4));
 #pragma unroll
         for (int part = 0; part < 2; ++part)
 #pragma unroll
-            for (int ks = 0; ks < CI / 2; ++ks)
-                b[part * (CI / 2) + ks] = bload(rs, in_lane + part * part_jump, (unsigned)(ks * 128));
+            for (int ks = 0; ks < CIH / 2; ++ks)
+                b[part * (CIH / 2) + ks] = bload(rs, in_lane + part * part_jump + (unsigned)(h * CIH * 64), (unsigned)(ks * 128));
     };
-    int pr = p0 + stream;
-    if (pr < p1) load_pair(pr, bc);
-    for (; pr < p1; pr += STREAMS) {
-        if (pr + STREAMS < p1) load_pair(pr + STREAMS, bn);
-        f32x16 k1, k2, k3;
+    f32x16 k1, k2, k3;
+    auto mac = [&](const float (&b)[CIH], int h) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { k1[r] = 0.f; k2[r] = 0.f; k3[r] = 0.f; }
-#pragma unroll
-        for (int kk = 0; kk < CI / 2; ++kk) {
-            const f32x4 w = *reinterpret_cast<const f32x4*>(wlane + kk * 256);
-            const float xr = bc[kk], xi = bc[CI / 2 + kk];
+        for (int kk = 0; kk < CIH / 2; ++kk) {
+            const f32x4 w = *reinterpret_cast<const f32x4*>(wlane + (h * (CIH / 2) + kk) * 256);
+            const float xr = b[kk], xi = b[CIH / 2 + kk];
             k1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[0], xr, k1, 0, 0, 0);
             k2 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[1], xi - xr, k2, 0, 0, 0);
             k3 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[2], xr + xi, k3, 0, 0, 0);
             if ((kk & 3) == 3) __builtin_amdgcn_sched_barrier(0);           // keep the LDS reads 4 k-steps ahead at most (registers)
+        }
+    };
+    int pr = p0 + stream;
+    if (pr < p1) load_pair(pr, 0, bc);
+    for (; pr < p1; pr += STREAMS) {
+        if constexpr (KH == 1) {
+            if (pr + STREAMS < p1) load_pair(pr + STREAMS, 0, bn);
+        } else {
+            load_pair(pr, 1, bn);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { k1[r] = 0.f; k2[r] = 0.f; k3[r] = 0.f; }
+        mac(bc, 0);
+        if constexpr (KH == 2) {
+            if (pr + STREAMS < p1) load_pair(pr + STREAMS, 0, bc);
+            mac(bn, 1);
         }
         const int have = min(2, p.N - 2 * pr);
         const __amdgpu_buffer_rsrc_t ro = rsrc_n(p.out + (size_t)(2 * pr) * out_sample, (unsigned)(have * out_sample * 4));
@@ -392,9 +420,11 @@ __global__ __launch_bounds__(256, 2) void dft_mix_kernel(MxParams p) {
             bstore(ro, out_lane[r], 0u, re[r]);
             bstore(ro, out_lane[r], im_jump, im[r]);          // (the uniform jump in the SGPR offset: the pair's descriptor covers it)
         }
-        if (pr + STREAMS < p1) {
+        if constexpr (KH == 1) {
+            if (pr + STREAMS < p1) {
 #pragma unroll
-            for (int kk = 0; kk < CI; ++kk) bc[kk] = bn[kk];
+                for (int kk = 0; kk < CI; ++kk) bc[kk] = bn[kk];
+            }
         }
     }
 }
@@ -412,13 +442,13 @@ struct WgParams {
     int N, Ci, Co, NF, nsplit;
 };
 
-template <int CT>             // tiles per side: Co / 32 = Ci / 32; block = CT * CT waves
-__global__ __launch_bounds__(64 * CT * CT) __attribute__((amdgpu_num_vgpr(128))) void dft_wgrad_kernel(WgParams p) {      // 4 waves per SIMD
+template <int CT, int CTN>    // tiles per side: Co / 32, Ci / 32 (Ci = 2 Co: the two phases of a stride-2 conv); block = CT * CTN waves
+__global__ __launch_bounds__(64 * CT * CTN) __attribute__((amdgpu_num_vgpr(128))) void dft_wgrad_kernel(WgParams p) {      // 4 waves per SIMD
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, half = lane >> 5;
     const int f = blockIdx.x, split = blockIdx.y;
-    const int wm = wave / CT, wn = wave % CT;
+    const int wm = wave / CTN, wn = wave % CTN;
     const int n0 = (int)((long long)p.N * split / p.nsplit), n1 = (int)((long long)p.N * (split + 1) / p.nsplit);
     const size_t ds_sample = (size_t)2 * p.NF * p.Co * 16, s_sample = (size_t)2 * p.NF * p.Ci * 16;
     // rows: real part at bin f, imaginary part NF rows further
@@ -592,7 +622,7 @@ int launch_gemm(DgParams p, hipStream_t st, const char* what) {
     const int mtiles = p.Mpad / 32;
     const int mg = pick_mg(mtiles, INV);
     const int groups = step::ceil_div(mtiles, mg);
-    const dim3 grid((unsigned)groups, (unsigned)(p.C / 8), (unsigned)(p.N * p.S));
+    const dim3 grid((unsigned)groups, (unsigned)(p.C * p.fs / 8), (unsigned)(p.N * p.S));
 #define DG_CASE(MGV) case MGV: hipLaunchKernelGGL((dft_gemm_kernel<MGV, INV>), grid, dim3(256), 0, st, p); return step::check_launch(what)
     if constexpr (INV) {
         switch (mg) { DG_CASE(2); DG_CASE(3); DG_CASE(4); default: break; }
@@ -653,8 +683,43 @@ extern "C" int step_dft_fwd_seg(const float* in, const float* in_scale, const fl
     DgParams p{};
     p.in = in; p.matt = matt; p.in_scale = in_scale; p.in_shift = in_shift; p.in_relu = in_relu; p.out = spec;
     p.N = N; p.C = C; p.K = K; p.Kpad = step::round_up((K + 1) / 2, KC); p.Mpad = step::round_up(rows / 2, 32); p.Mrows = rows;
-    p.S = S; p.seg_step = seg_step; p.frame0 = frame0; p.Tfull = T;
+    p.S = S; p.seg_step = seg_step; p.frame0 = frame0; p.Tfull = T; p.fs = 1;
     return launch_gemm<false>(p, (hipStream_t)stream, "step_dft_fwd");
+}
+
+// Phases: in (N, C, phases * Tp, 16) holds `phases` interleaved sequences of Tp frames per channel row (frame t of phase
+// ph at phases * t + ph); spec [N][rows][phases * C][16] takes the spectrum of sequence (c, ph) as channel phases * c + ph.
+extern "C" int step_dft_fwd_ph(const float* in, const float* in_scale, const float* in_shift, int in_relu,
+                               const float* matt, float* spec, int N, int C, int Tp, int rows, int phases, void* stream) {
+    STEP_REQUIRE(in && matt && spec, "step_dft_fwd_ph: null pointer");
+    STEP_REQUIRE(N >= 1 && N <= 65535 && C >= 8 && C % 8 == 0 && (phases == 1 || phases == 2) && C * phases / 8 <= 65535 &&
+                 Tp >= 1 && rows >= 32 && rows % 32 == 0,
+                 "step_dft_fwd_ph: bad shape N=%d C=%d Tp=%d rows=%d phases=%d", N, C, Tp, rows, phases);
+    STEP_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "step_dft_fwd_ph: scale/shift pair");
+    STEP_REQUIRE(((size_t)C * Tp + Tp + 64) * phases * 64 < (1ull << 31) && (size_t)rows * C * phases * 64 < (1ull << 31),
+                 "step_dft_fwd_ph: sample too large");
+    DgParams p{};
+    p.in = in; p.matt = matt; p.in_scale = in_scale; p.in_shift = in_shift; p.in_relu = in_relu; p.out = spec;
+    p.N = N; p.C = C; p.K = Tp; p.Kpad = step::round_up((Tp + 1) / 2, KC); p.Mpad = step::round_up(rows / 2, 32); p.Mrows = rows;
+    p.S = 1; p.seg_step = 0; p.frame0 = 0; p.Tfull = Tp; p.fs = phases;
+    return launch_gemm<false>(p, (hipStream_t)stream, "step_dft_fwd_ph");
+}
+
+// The inverse of step_dft_fwd_ph: spec [N][rows_in][phases * C][16] -> out (N, C, phases * Tp, 16), channel phases * c + ph of
+// the spectrum back to the frames phases * t + ph of channel c (no bias, statistics or tail: the input gradient of a strided conv).
+extern "C" int step_dft_inv_ph(const float* spec, const float* matt, float* out, int N, int C, int rows_in, int Tp,
+                               int phases, void* stream) {
+    STEP_REQUIRE(spec && matt && out, "step_dft_inv_ph: null pointer");
+    STEP_REQUIRE(N >= 1 && N <= 65535 && C >= 8 && C % 8 == 0 && (phases == 1 || phases == 2) && C * phases / 8 <= 65535 &&
+                 Tp >= 1 && rows_in >= 32 && rows_in % 32 == 0,
+                 "step_dft_inv_ph: bad shape N=%d C=%d rows=%d Tp=%d phases=%d", N, C, rows_in, Tp, phases);
+    STEP_REQUIRE(((size_t)C * Tp + Tp + 64) * phases * 64 < (1ull << 31) && (size_t)rows_in * C * phases * 64 < (1ull << 31),
+                 "step_dft_inv_ph: sample too large");
+    DgParams p{};
+    p.in = spec; p.matt = matt; p.out = out;
+    p.N = N; p.C = C; p.K = rows_in; p.Kpad = rows_in; p.Mpad = step::round_up((Tp + 1) / 2, 32); p.Mrows = Tp;
+    p.S = 1; p.seg_step = 0; p.frame0 = 0; p.Tfull = Tp; p.fs = phases;
+    return launch_gemm<true>(p, (hipStream_t)stream, "step_dft_inv_ph");
 }
 
 extern "C" int step_dft_fwd(const float* in, const float* in_scale, const float* in_shift, int in_relu,
@@ -680,7 +745,7 @@ extern "C" int step_dft_inv_seg(const float* spec, const float* matt, const floa
     p.out_scale = out_scale; p.out_shift = out_shift; p.res = res; p.res_scale = res_scale; p.res_shift = res_shift;
     p.out_relu = out_relu;
     p.N = N; p.C = C; p.K = rows_in; p.Kpad = rows_in; p.Mpad = step::round_up((T_seg + 1) / 2, 32); p.Mrows = T_seg;
-    p.S = S; p.seg_step = seg_step; p.frame0 = 0; p.Tfull = T_out;
+    p.S = S; p.seg_step = seg_step; p.frame0 = 0; p.Tfull = T_out; p.fs = 1;
     const int groups = step_dft_groups(T_seg);
     if (sums) {
         const size_t need = (size_t)N * S * groups * C * 2 * sizeof(double);
@@ -720,10 +785,11 @@ extern "C" int step_dft_wspec(const float* w, const float* tc, const float* ts, 
 
 extern "C" int step_dft_mix(const float* in, const float* wmat, float* out, int N, int Ci, int Co, int NF, void* stream) {
     STEP_REQUIRE(in && wmat && out, "step_dft_mix: null pointer");
-    STEP_REQUIRE(N >= 1 && (Ci == 32 || Ci == 64) && (Co == 32 || Co == 64) && NF >= 1,
-                 "step_dft_mix: unsupported N=%d Ci=%d Co=%d NF=%d", N, Ci, Co, NF);
+    const bool square = (Ci == 32 || Ci == 64) && (Co == 32 || Co == 64);
+    const bool rect = (Ci == 128 && Co == 64) || (Ci == 64 && Co == 128);          // the two phases of a stride-2 conv
+    STEP_REQUIRE(N >= 1 && (square || rect) && NF >= 1, "step_dft_mix: unsupported N=%d Ci=%d Co=%d NF=%d", N, Ci, Co, NF);
     MxParams p{in, wmat, out, N, Ci, Co, NF};
-    int ny = step::ceil_div(4096, NF);                   // ~8 rounds of 2 blocks per CU: no tail to speak of
+    int ny = step::ceil_div(rect ? 2048 : 4096, NF);     // ~8 rounds of 2 blocks (rect: 1 block of 8 waves) per CU: no tail to speak of
     const int npairs = (N + 1) / 2;
     ny = ny > step::ceil_div(npairs, 4) ? step::ceil_div(npairs, 4) : ny;
     ny = ny < 1 ? 1 : ny;
@@ -735,9 +801,11 @@ extern "C" int step_dft_mix(const float* in, const float* wmat, float* out, int 
     do {                                                                                                               \
         auto kern = dft_mix_kernel<CTV, CIV>;                                                                          \
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        if (e == hipSuccess) hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);                                    \
+        if (e == hipSuccess) hipLaunchKernelGGL(kern, grid, dim3(64 * mix_waves(CTV, CIV)), lds, st, p);               \
     } while (0)
-    if (Co == 64 && Ci == 64) MX_CASE(2, 64);
+    if (Co == 64 && Ci == 128) MX_CASE(2, 128);
+    else if (Co == 128) MX_CASE(4, 64);
+    else if (Co == 64 && Ci == 64) MX_CASE(2, 64);
     else if (Co == 64) MX_CASE(2, 32);
     else if (Ci == 64) MX_CASE(1, 64);
     else MX_CASE(1, 32);
@@ -749,31 +817,34 @@ extern "C" int step_dft_mix(const float* in, const float* wmat, float* out, int 
     return step::check_launch("step_dft_mix");
 }
 
-static int wgrad_nsplit(int N, int NF, int C) {
-    int ns = step::ceil_div(C == 32 ? 3072 : 768, NF);           // (32 channels: one wave per block)
+static int wgrad_nsplit(int N, int NF, int C, int Ci) {
+    // 64 channels: the block slots of the chip in one round (4 blocks of 4 waves per CU; Ci = 2 Co: 2 blocks of 8 waves); 32: one wave per block
+    int ns = C == 32 ? step::ceil_div(3072, NF) : (Ci == 2 * C ? 512 : 1024) / NF;     // 64 channels: the 1024 block slots of the chip (4 per CU) in one round; 32: one wave per block
     ns = ns > N ? N : ns;
     return ns < 1 ? 1 : ns;
 }
 extern "C" size_t step_dft_wgrad_ws_bytes(int N, int Ci, int Co, int NF) {
     if (N < 1 || Ci < 1 || Co < 1 || NF < 1) return 0;
-    return ((size_t)NF * wgrad_nsplit(N, NF, Co) * 3 * Ci * Co + (size_t)NF * 2 * Ci * Co) * sizeof(float);
+    return ((size_t)NF * wgrad_nsplit(N, NF, Co, Ci) * 3 * Ci * Co + (size_t)NF * 2 * Ci * Co) * sizeof(float);
 }
 
 extern "C" int step_dft_wgrad(const float* dspec, const float* spec, const float* tc, const float* ts, float* dw,
                               float* db, int N, int Ci, int Co, int NF, int Kt, int transposed, void* ws,
                               size_t ws_bytes, void* stream) {
     STEP_REQUIRE(dspec && spec && tc && ts && dw && ws, "step_dft_wgrad: null pointer");
-    STEP_REQUIRE(N >= 1 && (Ci == 32 || Ci == 64) && Co == Ci && NF >= 1 && Kt >= 1,
+    STEP_REQUIRE(N >= 1 && (Co == 32 || Co == 64) && (Ci == Co || Ci == 2 * Co) && NF >= 1 && Kt >= 1,
                  "step_dft_wgrad: unsupported N=%d Ci=%d Co=%d NF=%d Kt=%d", N, Ci, Co, NF, Kt);
     if (ws_bytes < step_dft_wgrad_ws_bytes(N, Ci, Co, NF)) {
         step::set_error("step_dft_wgrad: workspace %zu < %zu bytes", ws_bytes, step_dft_wgrad_ws_bytes(N, Ci, Co, NF));
         return STEP_ERR_WORKSPACE;
     }
     hipStream_t st = (hipStream_t)stream;
-    WgParams p{dspec, spec, (float*)ws, N, Ci, Co, NF, wgrad_nsplit(N, NF, Co)};
+    WgParams p{dspec, spec, (float*)ws, N, Ci, Co, NF, wgrad_nsplit(N, NF, Co, Ci)};
     const dim3 grid((unsigned)NF, (unsigned)p.nsplit);
-    if (Co == 64) hipLaunchKernelGGL((dft_wgrad_kernel<2>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((dft_wgrad_kernel<1>), grid, dim3(64), 0, st, p);
+    if (Co == 64 && Ci == 128) hipLaunchKernelGGL((dft_wgrad_kernel<2, 4>), grid, dim3(512), 0, st, p);
+    else if (Co == 64) hipLaunchKernelGGL((dft_wgrad_kernel<2, 2>), grid, dim3(256), 0, st, p);
+    else if (Ci == 64) hipLaunchKernelGGL((dft_wgrad_kernel<1, 2>), grid, dim3(128), 0, st, p);
+    else hipLaunchKernelGGL((dft_wgrad_kernel<1, 1>), grid, dim3(64), 0, st, p);
     int rc = step::check_launch("step_dft_wgrad");
     if (rc != STEP_OK) return rc;
     float* chat = (float*)ws + (size_t)NF * p.nsplit * 3 * Ci * Co;

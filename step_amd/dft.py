@@ -4,12 +4,19 @@ float64 with integer-reduced angles and cached per shape and device, and the thr
 Same statements of the reference as ops.tcn_conv / ops.tcn_wgrad: tcn[2] of st_gcn / st_gctn
 (classifier_stgcn_real_only/net/classifier.py:156-162, generator_cvae/net/CVAE_stgcn.py:359-365) and its gradients."""
 import math
+import os
 
 import torch
 
 from . import _lib
 
 _TABLES = {}
+
+
+def _require(ok, msg):
+    """shapes are checked here, on the host: the kernels trust their arguments"""
+    if not ok:
+        raise _lib.StepHipError("dft." + msg)
 
 
 def supported(C, Kt):
@@ -113,9 +120,62 @@ def tap_tables(T, Kt, T_out, stride, device, d2=None):
     return _TABLES[key]
 
 
+# ------------------------------------------------------------------ stride 2 as two stride-1 convs (polyphase)
+def phases(C, T, Kt, stride, transposed):
+    """2 when the conv runs as two stride-1 convs on the even and the odd input frames, else 1.  Output frame t' of a
+    stride-2 conv reads the frames 2 t' + d, d = j - P: the taps with even d meet the even frames (phase 0) at offset
+    m = d / 2, the taps with odd d the odd frames (phase 1) at m = (d - 1) / 2, so
+        u[t'] = SUM_ph SUM_m w_ph[m] a_ph[t' + m]
+    is a stride-1 correlation of Tp = T / 2 frames with |m| <= ceil(P / 2): every transform works on half the frames
+    and ~half the bins (T = 240, Kt = 75: 160 rows instead of 288), the mixing takes 2 C -> C channels per bin."""
+    if os.environ.get("STEP_DFT_NO_PHASES"):            # same-box A/B against the strided-matrix form
+        return 1
+    return 2 if (stride == 2 and not transposed and T % 2 == 0 and C in (32, 64) and Kt >= 3) else 1
+
+
+def phase_geometry(T, Kt):
+    """(Tp, Ktp): frames per phase and the tap extent 2 ceil(P / 2) + 1 that sets the phase grid's length"""
+    P = (Kt - 1) // 2
+    return T // 2, 2 * ((P + 1) // 2) + 1
+
+
+def _phase_taps(Kt, device):
+    """per tap j: its phase (d mod 2) as masks [2][Kt] and its offset m within the phase"""
+    key = ("phase_taps", Kt, str(device))
+    if key not in _TABLES:
+        d = torch.arange(Kt) - (Kt - 1) // 2
+        ph = torch.remainder(d, 2)
+        m = (d - ph) // 2
+        masks = torch.stack((ph == 0, ph == 1)).to(torch.float32).to(device)
+        _TABLES[key] = (masks, m)
+    return _TABLES[key]
+
+
+def phase_tap_tables(T, Kt, device):
+    """tc / ts [NF][Kt] on the phase grid: column j = cos / sin of 2 pi f m_j / L (input and output share their origin)"""
+    key = ("phase_tap_tables", T, Kt, str(device))
+    if key not in _TABLES:
+        Tp, Ktp = phase_geometry(T, Kt)
+        rows, NF, L = geometry(Tp, Ktp)
+        ang = _angles2(torch.arange(NF), 2 * _phase_taps(Kt, device)[1], L)
+        _TABLES[key] = (torch.cos(ang).to(torch.float32).to(device).contiguous(),
+                        torch.sin(ang).to(torch.float32).to(device).contiguous())
+    return _TABLES[key]
+
+
 def weight_spectrum(w, C, T, Kt, transposed, T_out=None, stride=1):
     """(forward, backward) mixing weights (NF * 4 C^2 floats each: the triples of csrc/tcn_dft.hip) of the taps w (Co,Ci,Kt,1) [or (Ci,Co,Kt,1) when transposed]
     for a conv from T frames to T_out frames at `stride`"""
+    if phases(C, T, Kt, stride, transposed) == 2:
+        Tp, Ktp = phase_geometry(T, Kt)
+        rows, NF, L = geometry(Tp, Ktp)
+        tc, ts = phase_tap_tables(T, Kt, w.device)
+        masks = _phase_taps(Kt, w.device)[0]
+        w2 = (w.reshape(C, C, 1, Kt) * masks.view(1, 1, 2, Kt)).reshape(C, 2 * C, Kt)      # (Co, 2 ci + ph, Kt)
+        wf = torch.empty(NF * 4 * C * 2 * C, dtype=torch.float32, device=w.device)
+        wb = torch.empty_like(wf)
+        _lib.call("step_dft_wspec", w2, tc, ts, wf, wb, 2 * C, C, NF, Kt, 0)
+        return wf, wb
     rows, NF, L = geometry(T, Kt)
     tc, ts = tap_tables(T, Kt, T if T_out is None else T_out, stride, w.device)
     wf = torch.empty(NF * 4 * C * C, dtype=torch.float32, device=w.device)
@@ -133,11 +193,25 @@ def transform(x, scale, shift, relu, step, T, Kt):
     return spec
 
 
-def mix(spec, wmat, C):
+def mix(spec, wmat, C, Co=None):
+    """per-bin channel mixing of spec [N][rows][C][16] -> [N][rows][Co][16] (Co = C unless given: the two phases)"""
     N, rows = spec.shape[0], spec.shape[1]
-    out = torch.empty_like(spec)
-    _lib.call("step_dft_mix", spec, wmat, out, N, C, C, rows // 2)
+    Co = C if Co is None else Co
+    _require(tuple(spec.shape[2:]) == (C, 16) and wmat.numel() == (rows // 2) * 4 * C * Co,
+             "mix: spectrum %s / %d weights do not belong to a %d -> %d mixing of %d bins" % (tuple(spec.shape), wmat.numel(), C, Co, rows // 2))
+    out = torch.empty((N, rows, Co, 16), dtype=torch.float32, device=spec.device)
+    _lib.call("step_dft_mix", spec, wmat, out, N, C, Co, rows // 2)
     return out
+
+
+def transform_phases(x, scale, shift, relu, T, Kt):
+    """spectrum [N][rows][2 C][16] of the even and the odd frames of act(x) (N,C,T,16) (channel 2 c + ph)"""
+    N, C = x.shape[0], x.shape[1]
+    Tp, Ktp = phase_geometry(T, Kt)
+    rows, NF, L = geometry(Tp, Ktp)
+    spec = torch.empty((N, rows, 2 * C, 16), dtype=torch.float32, device=x.device)
+    _lib.call("step_dft_fwd_ph", x, scale, shift, int(relu), fwd_matrix(Tp, 1, Tp, Ktp, x.device), spec, N, C, Tp, rows, 2)
+    return spec
 
 
 def inverse(spec, bias, T_out, step, T, Kt, sums=None, epilogue=None):
@@ -145,6 +219,8 @@ def inverse(spec, bias, T_out, step, T, Kt, sums=None, epilogue=None):
     statistics of the result (SUM, SUM of squares per channel); epilogue: (out_scale, out_shift, res, res_scale,
     res_shift, relu) - the eval-mode tail of a block"""
     N, rows, C, V = spec.shape
+    _require(rows == geometry(T, Kt)[0] and V == 16 and step * (T_out - 1) < T,
+             "inverse: spectrum %s for T = %d, Kt = %d, %d frames at step %d" % (tuple(spec.shape), T, Kt, T_out, step))
     out = torch.empty((N, C, T_out, 16), dtype=torch.float32, device=spec.device)
     ws, nb = None, 0
     if sums is not None:
@@ -156,22 +232,57 @@ def inverse(spec, bias, T_out, step, T, Kt, sums=None, epilogue=None):
     return out
 
 
-def conv_forward(y, scale, shift, relu, wf, bias, T_out, stride, Kt, sums=None, epilogue=None):
-    """u = conv(act(y)) + bias -> (u, spectrum of act(y)); wf from weight_spectrum"""
+def conv_forward(y, scale, shift, relu, wf, bias, T_out, stride, Kt, sums=None, epilogue=None, transposed=False):
+    """u = conv(act(y)) + bias -> (u, spectrum of act(y)); wf from weight_spectrum (same T, stride, transposed)"""
     N, C, T, V = y.shape
+    if phases(C, T, Kt, stride, transposed) == 2:
+        Tp, Ktp = phase_geometry(T, Kt)
+        sa = transform_phases(y, scale, shift, relu, T, Kt)
+        u = inverse(mix(sa, wf, 2 * C, C), bias, T_out, 1, Tp, Ktp, sums, epilogue)
+        return u, sa
     sa = transform(y, scale, shift, relu, 1, T, Kt)
     u = inverse(mix(sa, wf, C), bias, T_out, stride, T, Kt, sums, epilogue)
     return u, sa
 
 
-def conv_dgrad(sdu, wb, T, Kt):
+def transform_dout(du, stride, T, Kt, transposed=False):
+    """spectrum of the output gradient du (N,C,T_out,16) of a conv over T input frames"""
+    C = du.shape[1]
+    if phases(C, T, Kt, stride, transposed) == 2:
+        Tp, Ktp = phase_geometry(T, Kt)                 # T_out = Tp frames on the phase grid
+        return transform(du, None, None, False, 1, Tp, Ktp)
+    return transform(du, None, None, False, stride, T, Kt)
+
+
+def conv_dgrad(sdu, wb, T, Kt, stride=1, transposed=False):
     """gradient with respect to the activated input, (N,C,T,16), from the spectrum of dout"""
-    C = sdu.shape[2]
+    N, rows, C, V = sdu.shape
+    if phases(C, T, Kt, stride, transposed) == 2:
+        Tp, Ktp = phase_geometry(T, Kt)
+        _require(rows == geometry(Tp, Ktp)[0], "conv_dgrad: the spectrum of dout is not on the phase grid (transform_dout)")
+        sda = mix(sdu, wb, C, 2 * C)
+        da = torch.empty((N, C, T, 16), dtype=torch.float32, device=sdu.device)
+        _lib.call("step_dft_inv_ph", sda, inv_matrix(Tp, 1, Tp, Ktp, sdu.device), da, N, C, rows, Tp, 2)
+        return da
+    _require(rows == geometry(T, Kt)[0], "conv_dgrad: spectrum rows %d for T = %d" % (rows, T))
     return inverse(mix(sdu, wb, C), None, T, 1, T, Kt)
 
 
 def conv_wgrad(sdu, sa, T, Kt, transposed, wshape, T_out=None, stride=1):
-    N, rows, C, V = sa.shape
+    N, rows, C, V = sdu.shape
+    ph = phases(C, T, Kt, stride, transposed)
+    _require(tuple(sa.shape) == (N, rows, ph * C, 16) and V == 16,
+             "conv_wgrad: spectra %s (dout) / %s (input) do not belong to this conv (%d phase(s))" % (tuple(sdu.shape), tuple(sa.shape), ph))
+    if ph == 2:
+        tc, ts = phase_tap_tables(T, Kt, sa.device)
+        dw2 = torch.empty((C, 2 * C, Kt), dtype=torch.float32, device=sa.device)
+        db = torch.empty(C, dtype=torch.float32, device=sa.device)
+        nb = _lib.query("step_dft_wgrad_ws_bytes", N, 2 * C, C, rows // 2)
+        ws = torch.empty(nb, dtype=torch.uint8, device=sa.device)
+        _lib.call("step_dft_wgrad", sdu, sa, tc, ts, dw2, db, N, 2 * C, C, rows // 2, Kt, 0, ws, nb)
+        odd = _phase_taps(Kt, sa.device)[0][1].view(1, 1, Kt) > 0           # every tap's gradient sits in its own phase
+        dw2 = dw2.view(C, C, 2, Kt)
+        return torch.where(odd, dw2[:, :, 1], dw2[:, :, 0]).reshape(wshape), db
     tc, ts = tap_tables(T, Kt, T if T_out is None else T_out, stride, sa.device)
     dw = torch.empty(wshape, dtype=torch.float32, device=sa.device)
     db = torch.empty(C, dtype=torch.float32, device=sa.device)

@@ -426,7 +426,7 @@ class StGcnBlockFn(torch.autograd.Function):
             # frequency domain: the spectrum of relu(bn1(y)) is kept for the weight gradient
             wf_dft, wb_dft = _dft_mod.weight_spectrum(tcn_w, Co, T, Kt, s.transposed, To, st)
             usums = torch.empty(2 * Co + 1, dtype=torch.float64, device=dev) if (training and _FUSED_STATS) else None
-            u, sa = _dft_mod.conv_forward(y, s1, h1, True, wf_dft, tcn_b, To, st, Kt, usums)
+            u, sa = _dft_mod.conv_forward(y, s1, h1, True, wf_dft, tcn_b, To, st, Kt, usums, transposed=s.transposed)
             del wf_dft
             if not need_grad:
                 sa = wb_dft = None
@@ -522,7 +522,7 @@ class StGcnBlockFn(torch.autograd.Function):
             wf_dft = cached(c, "wf_dft", tensor_key(tcn_w) + (T, To, st, int(s.transposed)),
                             lambda: _dft_mod.weight_spectrum(tcn_w, Co, T, Kt, s.transposed, To, st)[0])
             out, _ = _dft_mod.conv_forward(y, s1, h1, True, wf_dft, tcn_b, To, st, Kt,
-                                           epilogue=(s2, h2, res_t, sr, hr, True))
+                                           epilogue=(s2, h2, res_t, sr, hr, True), transposed=s.transposed)
             return out
         wp = cached(c, "wp", tensor_key(tcn_w) + (str(bf), mode, st),
                     lambda: tcn_pack(tcn_w, Co, Co, Kt, st, mode, bf16=bf))
@@ -552,10 +552,10 @@ class StGcnBlockFn(torch.autograd.Function):
 
         # temporal conv
         if sa is not None:
-            sdu = _dft_mod.transform(du, None, None, False, st, T, Kt)
+            sdu = _dft_mod.transform_dout(du, st, T, Kt, s.transposed)
             del du
             dtw, dtb = _dft_mod.conv_wgrad(sdu, sa, T, Kt, s.transposed, tuple(tcn_w.shape), To, st)
-            da = _dft_mod.conv_dgrad(sdu, wb_dft, T, Kt)
+            da = _dft_mod.conv_dgrad(sdu, wb_dft, T, Kt, st, s.transposed)
             del sdu
         else:
             dtw, dtb = tcn_wgrad(du, y, s1, h1, True, N, Co, Co, T, To, Kt, st, s.transposed, tcn_w.shape,

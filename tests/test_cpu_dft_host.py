@@ -87,6 +87,54 @@ def test_tables_reproduce_the_temporal_conv_and_its_gradients(T, stride, Kt):
     assert np.abs(dw - dw_ref.numpy().ravel()).max() < 2e-5 * max(1.0, np.abs(dw_ref.numpy()).max())
 
 
+@pytest.mark.parametrize("T,Kt", [(240, 75), (18, 75), (60, 9), (150, 75), (2, 3)])
+def test_phase_tables_reproduce_the_stride_2_conv_and_its_gradients(T, Kt):
+    """stride 2 as two stride-1 convs on the even / odd frames (dft.phases): the tap split (_phase_taps), the phase tap
+    tables and the phase grid's geometry, in numpy against the oracle's strided conv and both gradients"""
+    assert dft.phases(64, T, Kt, 2, False) == 2 and dft.phases(64, T + 1, Kt, 2, False) == 1
+    assert dft.phases(64, T, Kt, 2, True) == 1 and dft.phases(64, T, Kt, 1, False) == 1
+    rng = np.random.default_rng(T + Kt)
+    To = T // 2
+    a, w, du = rng.standard_normal(T), rng.standard_normal(Kt) * 0.1, rng.standard_normal(To)
+    at = torch.tensor(a).view(1, 1, T, 1).requires_grad_(True)
+    wt = torch.tensor(w).view(1, 1, Kt, 1).requires_grad_(True)
+    u = stgcn.temporal_conv(at, wt, None, 2, False)
+    assert u.shape[2] == To
+    da_ref, dw_ref = torch.autograd.grad(u, (at, wt), torch.tensor(du).view(1, 1, To, 1))
+    Tp, Ktp = dft.phase_geometry(T, Kt)
+    P = (Kt - 1) // 2
+    assert Tp == To and Ktp == 2 * ((P + 1) // 2) + 1
+    rows, NF, L = dft.geometry(Tp, Ktp)
+    assert L >= Tp + (P + 1) // 2
+    masks, m = dft._phase_taps(Kt, "cpu")
+    masks = masks.double().numpy()
+    d = np.arange(Kt) - P
+    assert ((2 * m.numpy() + masks[1]) == d).all() and (masks.sum(0) == 1).all()      # frame 2 t' + d = 2 (t' + m) + phase
+    tc, ts = (t.double().numpy() for t in dft.phase_tap_tables(T, Kt, "cpu"))
+    W = [tc @ (w * masks[ph]) + 1j * (ts @ (w * masks[ph])) for ph in range(2)]
+    A = []
+    for ph in range(2):
+        re, im = transform(a[ph::2], 1, Tp, Ktp)
+        A.append(re + 1j * im)
+    R = W[0] * A[0] + W[1] * A[1]
+    tol = 2e-5 * max(1.0, np.abs(u.detach().numpy()).max())
+    assert np.abs(inverse(R.real, R.imag, To, 1, Tp, Ktp) - u.detach().numpy().ravel()).max() < tol
+    dre, dim_ = transform(du, 1, Tp, Ktp)
+    D = dre + 1j * dim_
+    da = np.zeros(T)
+    for ph in range(2):
+        dA = np.conj(W[ph]) * D
+        da[ph::2] = inverse(dA.real, dA.imag, Tp, 1, Tp, Ktp)
+    assert np.abs(da - da_ref.numpy().ravel()).max() < 2e-5 * max(1.0, np.abs(da_ref.numpy()).max())
+    kap = np.full(NF, 2.0 / L)
+    kap[0] = 1.0 / L
+    dw = np.zeros(Kt)
+    for ph in range(2):
+        C = np.conj(D) * A[ph]
+        dw += masks[ph] * ((kap * C.real) @ tc - (kap * C.imag) @ ts)
+    assert np.abs(dw - dw_ref.numpy().ravel()).max() < 2e-5 * max(1.0, np.abs(dw_ref.numpy()).max())
+
+
 def test_cost_model_and_geometry():
     # 75 taps: the frequency-domain path at every sequence length BASELINE.json names; 9 taps and 3 channels: direct
     for C in (32, 64):

@@ -12,7 +12,9 @@ D = "cuda:0"
 
 CASES = [(64, 1, 33, 2, False, 75), (32, 1, 50, 3, False, 75), (64, 2, 41, 2, False, 75), (64, 2, 240, 3, False, 75),
          (64, 1, 120, 5, False, 75), (32, 1, 24, 2, True, 75), (64, 1, 75, 4, True, 75), (64, 1, 18, 3, False, 75),
-         (64, 2, 120, 3, False, 9), (32, 1, 240, 2, False, 9), (64, 1, 300, 2, False, 75)]
+         (64, 2, 120, 3, False, 9), (32, 1, 240, 2, False, 9), (64, 1, 300, 2, False, 75),
+         # stride 2 with an even T runs as two stride-1 convs on the even / odd frames (dft.phases): 2 C -> C mixing
+         (32, 2, 60, 3, False, 75), (64, 2, 18, 5, False, 75), (32, 2, 240, 2, False, 9), (64, 2, 150, 1, False, 75)]
 
 
 @pytest.mark.parametrize("C,stride,T,N,tr,Kt", CASES)
@@ -35,20 +37,22 @@ def test_dft_conv_forward_dgrad_wgrad_vs_oracle(C, stride, T, N, tr, Kt):
     yd, wd, bd, scd, shd, dud = (t.to(D) for t in (y, w, b, sc, sh, du))
     wf, wb = dft.weight_spectrum(wd, C, T, Kt, tr, To, stride)
     sums = torch.zeros(2 * C + 1, dtype=torch.float64, device=D)
-    u, sa = dft.conv_forward(yd, scd, shd, True, wf, bd, To, stride, Kt, sums)
+    u, sa = dft.conv_forward(yd, scd, shd, True, wf, bd, To, stride, Kt, sums, transposed=tr)
+    assert dft.phases(C, T, Kt, stride, tr) == (2 if stride == 2 and T % 2 == 0 else 1)
+    assert sa.shape[2] == C * dft.phases(C, T, Kt, stride, tr)
     assert_close(u, u64, 1e-4, "u")
     ud = u.double()
     got = sums[:2 * C].view(C, 2)
     assert float((got[:, 0] - ud.sum(dim=(0, 2, 3))).abs().max()) <= 2e-6 * float(ud.abs().sum(dim=(0, 2, 3)).max())
     assert float(((got[:, 1] - (ud * ud).sum(dim=(0, 2, 3))) / (ud * ud).sum(dim=(0, 2, 3))).abs().max()) <= 2e-6
-    sdu = dft.transform(dud, None, None, False, stride, T, Kt)
-    da = dft.conv_dgrad(sdu, wb, T, Kt)
+    sdu = dft.transform_dout(dud, stride, T, Kt, tr)
+    da = dft.conv_dgrad(sdu, wb, T, Kt, stride, tr)
     assert_close(da, da64, 1e-4, "da")
     dw, db = dft.conv_wgrad(sdu, sa, T, Kt, tr, tuple(w.shape), To, stride)
     assert_close(dw, dw64, 1e-4, "dw")
     assert_close(db, db64, 1e-4, "db")
     # no statistics asked, no activation: the plain paths
-    u2, _ = dft.conv_forward(yd, None, None, False, wf, None, To, stride, Kt)
+    u2, _ = dft.conv_forward(yd, None, None, False, wf, None, To, stride, Kt, transposed=tr)
     assert_close(u2, stgcn.temporal_conv(y.double(), w.double(), None, stride, tr), 1e-4, "u, plain")
 
 

@@ -43,27 +43,40 @@ def main():
     w = (torch.randn(c, c, kt, 1, generator=g) * 0.02).to(d)
     b = torch.zeros(c, device=d)
     sc, sh = torch.ones(c, device=d), torch.zeros(c, device=d)
-    rows, NF, L = dft.geometry(t, kt)
+    ph = dft.phases(c, t, kt, s, False)
+    if ph == 2:
+        tp, ktp = dft.phase_geometry(t, kt)
+        rows, NF, L = dft.geometry(tp, ktp)
+    else:
+        tp, ktp = t, kt
+        rows, NF, L = dft.geometry(t, kt)
     wf, wb = dft.weight_spectrum(w, c, t, kt, False, to, s)
     sums = torch.zeros(2 * c + 1, dtype=torch.float64, device=d)
     want = lambda *names: not a.only or any(a.only in x for x in names)      # set up only what the chosen stages read
-    sa = dft.transform(y, sc, sh, True, 1, t, kt) if want("fwd: mix", "bwd: wgrad", "fwd: inverse(+stats)") or not a.only else None
-    sm = dft.mix(sa, wf, c) if want("fwd: inverse(+stats)") else None
-    sdu = dft.transform(du, None, None, False, s, t, kt) if want("bwd: mix", "bwd: inverse", "bwd: wgrad") else None
-    smb = dft.mix(sdu, wb, c) if want("bwd: inverse") else None
+    tr_a = (lambda: dft.transform_phases(y, sc, sh, True, t, kt)) if ph == 2 else (lambda: dft.transform(y, sc, sh, True, 1, t, kt))
+    mix_f = (lambda: dft.mix(sa, wf, 2 * c, c)) if ph == 2 else (lambda: dft.mix(sa, wf, c))
+    inv_f = (lambda: dft.inverse(sm, b, to, 1, tp, ktp, sums)) if ph == 2 else (lambda: dft.inverse(sm, b, to, s, t, kt, sums))
+    mix_b = (lambda: dft.mix(sdu, wb, c, 2 * c)) if ph == 2 else (lambda: dft.mix(sdu, wb, c))
+    sa = tr_a() if want("fwd: mix", "bwd: wgrad", "fwd: inverse(+stats)") or not a.only else None
+    sm = mix_f() if want("fwd: inverse(+stats)") else None
+    sdu = dft.transform_dout(du, s, t, kt) if want("bwd: mix", "bwd: inverse", "bwd: wgrad") else None
+    smb = mix_b() if want("bwd: inverse") else None
+    inv_b = (lambda: dft._lib.call("step_dft_inv_ph", smb, dft.inv_matrix(tp, 1, tp, ktp, d), torch.empty_like(y), n, c, rows, tp, 2)) \
+        if ph == 2 else (lambda: dft.inverse(smb, None, t, 1, t, kt))
     fl = 2.0 * c * c * kt * to * 16 * n
+    fin = t if ph == 1 else t          # frames a full-rate transform handles (both phases together)
     stages = [
         ("wspec", lambda: dft.weight_spectrum(w, c, t, kt, False, to, s), 0),
-        ("fwd: transform(a)", lambda: dft.transform(y, sc, sh, True, 1, t, kt), 1.0 * rows * t * c * 16 * n),
-        ("fwd: mix", lambda: dft.mix(sa, wf, c), 2.0 * 3 * c * c * 16 * NF * n),
-        ("fwd: inverse(+stats)", lambda: dft.inverse(sm, b, to, s, t, kt, sums), 1.0 * rows * to * c * 16 * n),
-        ("bwd: transform(du)", lambda: dft.transform(du, None, None, False, s, t, kt), 1.0 * rows * to * c * 16 * n),
-        ("bwd: mix", lambda: dft.mix(sdu, wb, c), 2.0 * 3 * c * c * 16 * NF * n),
-        ("bwd: inverse", lambda: dft.inverse(smb, None, t, 1, t, kt), 1.0 * rows * t * c * 16 * n),
-        ("bwd: wgrad", lambda: dft.conv_wgrad(sdu, sa, t, kt, False, tuple(w.shape), to, s), 2.0 * 3 * c * c * 16 * NF * n),
+        ("fwd: transform(a)", tr_a, 1.0 * rows * fin * c * 16 * n),
+        ("fwd: mix", mix_f, 2.0 * 3 * c * c * ph * 16 * NF * n),
+        ("fwd: inverse(+stats)", inv_f, 1.0 * rows * to * c * 16 * n),
+        ("bwd: transform(du)", lambda: dft.transform_dout(du, s, t, kt), 1.0 * rows * to * c * 16 * n),
+        ("bwd: mix", mix_b, 2.0 * 3 * c * c * ph * 16 * NF * n),
+        ("bwd: inverse", inv_b, 1.0 * rows * fin * c * 16 * n),
+        ("bwd: wgrad", lambda: dft.conv_wgrad(sdu, sa, t, kt, False, tuple(w.shape), to, s), 2.0 * 3 * c * c * ph * 16 * NF * n),
     ]
     tot = {"fwd": 0.0, "bwd": 0.0}
-    print("C=%d s=%d T=%d N=%d Kt=%d: rows=%d L=%d, spectrum %.2f GB" % (c, s, t, n, kt, rows, L, n * rows * c * 64 / 1e9))
+    print("C=%d s=%d T=%d N=%d Kt=%d phases=%d: rows=%d L=%d, spectrum of the input %.2f GB" % (c, s, t, n, kt, ph, rows, L, n * rows * c * ph * 64 / 1e9))
     for name, fn, flops in stages:
         if a.only and a.only not in name:
             continue
