@@ -553,6 +553,13 @@ def main():
         roof = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"],
                 "peak": PEAK_BF16_MFMA_TFLOPS if args.mfma == "bf16" else PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": dom["frac"], "traffic": traffic, "traffic_source": traffic_src,
                 "flops_per_launch": dom.get("flops_per_launch", direct_flops)}
+        if dom.get("frac_hbm", 0.0) > dom["frac"]:
+            # the frequency-domain stages stream a spectrum per launch: where the bytes' fraction of the HBM peak exceeds
+            # the FLOPs' fraction of the MFMA peak, HBM is the binding roof (the other fraction is kept beside it)
+            roof.update({"bound": "hbm", "achieved": dom["gbs"], "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": dom["frac_hbm"],
+                         "bytes_per_launch": round(dom["gbs"] * dom["ms"] * 1e6), "mfma_tflops": dom["tflops"], "frac_mfma": dom["frac"]})
+        elif "frac_hbm" in dom:
+            roof.update({"hbm_gbs": dom["gbs"], "frac_hbm": dom["frac_hbm"]})
         if direct_run is not None:
             td, tsd = pmc_traffic(dom_direct["kernel"], args.batch, args.frames)
             direct_run["roofline"] = {"bound": "mfma", "kernel": dom_direct["kernel"], "achieved": dom_direct["tflops"],

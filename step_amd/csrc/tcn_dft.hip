@@ -14,7 +14,7 @@
 //   a^[ci,f]   = SUM_t a[ci,t] e^{-2 pi i f t / L}                              step_dft_fwd   (matrix F, [2 NF x T])
 //   r^[co,f]   = SUM_ci w^[co,ci,f] a^[ci,f],  w^[f] = SUM_j w[j] e^{+2 pi i f (j-P)/L}   step_dft_mix   (per bin f; 3 real products)
 //   u[co,t']   = SUM_f kappa_f / L Re(r^[co,f] e^{+2 pi i f s t'/L}) + b[co]     step_dft_inv   (matrix G, [To x 2 NF])
-// L = 2 NF - 1 is odd (no Nyquist bin; kappa_0 = 1, kappa_f = 2), 2 NF = round_up(T + P + 1, 32); the circular
+// L = 2 NF - 1 is odd (no Nyquist bin; kappa_0 = 1, kappa_f = 2), 2 NF = round_up(T + P + 1, 4) (NF even); the circular
 // correlation equals the linear one on tau in [0, T) because L >= T + P.  Backward:
 //   du^[co,f]  = SUM_t' du[co,t'] e^{-2 pi i f s t'/L}                          step_dft_fwd   (matrix with rows at s t')
 //   da^[ci,f]  = SUM_co conj(w^[co,ci,f]) du^[co,f];  da = inverse at full rate  step_dft_mix + step_dft_inv
@@ -24,6 +24,7 @@
 // tensor they come from; a^ of the forward pass is kept for the weight gradient.  The cos / sin matrices and the tap
 // tables are built by the host in float64 with integer-reduced angles (step_amd/dft.py) and passed in.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -81,7 +82,8 @@ struct DgParams {
     // for phase ph of channel c (a wave's 2 x 16 lanes then touch 128 contiguous bytes of the tensor: frames 2 t and
     // 2 t + 1 of one channel), every one an ordinary spectrum of its Tfull frames.  fs = 1: one sequence per row.
     int fs;
-    int N, C, K, Kpad, Mpad, Mrows;   // INV == 0: K frames, Kpad = round_up(ceil(K/2), KC), Mrows = 2 NF; INV == 1: K = Kpad = 2 NF, Mrows = T_out
+    int N, C, K, Kpad, Mpad, Mrows;   // INV == 0: K frames, Kpad = round_up(ceil(K/2), KC), Mrows = 2 NF; INV == 1: K = 2 NF rows of the
+                                      // spectrum, Kpad = 2 round_up(NF, KC): the table holds each half (Re, Im) padded with zero rows to whole chunks, Mrows = T_out
 };
 
 // slots per k in the table for W row tiles: fours, then a pair (3 -> 4)
@@ -154,6 +156,11 @@ __global__ __launch_bounds__(256, 2) void dft_gemm_kernel(DgParams p) {
     };
     constexpr int NB = INV ? KC / 2 : KC;              // INV == 0: pair sums, then pair differences
     float bcur[NB], bnxt[NB];
+    // INV: table k -> row of the spectrum: the Im half starts kpadh = round_up(NF, KC) - NF rows early; rows of a half's
+    // zero padding are read from the last real pair of rows instead (finite values times the table's zeros; NF is even,
+    // so a pair of rows is never half padding)
+    [[maybe_unused]] const int nre = nchunk >> 1;
+    [[maybe_unused]] const int kpadh = (p.Kpad - p.K) >> 1;
     auto load_b = [&](int kc, float (&b)[NB]) {
         if constexpr (!INV) {
             // a chunk whose 16 pairs all have both frames (every chunk but the last, and the first of a segment at the
@@ -177,7 +184,8 @@ __global__ __launch_bounds__(256, 2) void dft_gemm_kernel(DgParams p) {
         for (int ks = 0; ks < KC / 2; ++ks) {
             const int k = kc * KC + 2 * ks;                                  // (+ half: in the lane offsets)
             if constexpr (INV) {
-                b[ks] = bload(rs, voff, (unsigned)k * kstride);
+                const int row = min(k - (kc >= nre ? kpadh : 0), p.K - 2);
+                b[ks] = bload(rs, voff, (unsigned)row * kstride);
             } else {
                 float xh = bload(rs, voff + (unsigned)k * fb, 0u);      // (offsets in the VGPR: the range check sees all of them)
                 float xl = bload(rs, voff_lo - (unsigned)k * fb, 0u);
@@ -231,7 +239,6 @@ __global__ __launch_bounds__(256, 2) void dft_gemm_kernel(DgParams p) {
     if constexpr (!INV) {
         for (int kc = 0; kc < nchunk; ++kc) chunk(kc, acc);
     } else {
-        const int nre = nchunk >> 1;                                          // K = 2 NF, NF a multiple of KC
         for (int kc = 0; kc < nre; ++kc) chunk(kc, acc);
         for (int kc = nre; kc < nchunk; ++kc) chunk(kc, acc + MG);
     }
@@ -636,16 +643,18 @@ int launch_gemm(DgParams p, hipStream_t st, const char* what) {
 
 }  // namespace
 
-// rows of a spectrum for a tensor of T frames and a Kt-tap kernel: 2 NF = round_up(T + (Kt-1)/2 + 1, 32); L = 2 NF - 1
+// rows of a spectrum for a tensor of T frames and a Kt-tap kernel: 2 NF = round_up(T + (Kt-1)/2 + 1, 4) (NF even: the
+// inverse reads the rows in pairs); L = 2 NF - 1 >= T + (Kt-1)/2
 extern "C" int step_dft_rows(int T, int Kt) {
     if (T < 1 || Kt < 1 || (Kt & 1) == 0) return 0;
-    return step::round_up(T + (Kt - 1) / 2 + 1, 32);
+    static const int gran = getenv("STEP_DFT_ROWS32") ? 32 : 4;       // (same-box A/B against the coarser grid of the first version)
+    return step::round_up(T + (Kt - 1) / 2 + 1, gran);
 }
 
 // layout of the matrices step_dft_fwd / step_dft_inv read (one layout for both kernel forms).  `rows` = the matrix's output rows: NF for each half (cos,
 // sin) of the forward matrix, ceil(T_out / 2) pairs for the inverse.  A matrix of `rows` rows is tiled
 // [groups][Kpad][mgp x 32] floats: tile slot i of group g is M[row (g * mg + i) * 32 + l][k], zero where the row or k does
-// not exist (Kpad = round_up(ceil(K / 2), 16) forward, 2 NF inverse); in the forward table slots i < mg hold the cos
+// not exist (Kpad = round_up(ceil(K / 2), 16) forward; inverse: 2 round_up(NF, 16), the Re rows and the Im rows each padded to whole chunks of 16); in the forward table slots i < mg hold the cos
 // half's tiles and slots mg + i the sin half's.  Per k the slots are stored in fours, [q][l < 32][4], then (mgp % 4 == 2)
 // a last pair [l][2]: every LDS read is 16 (8) bytes per lane at a lane stride of 16 (8) bytes.  Returns mg, *mgp = the
 // slot count per k (3 tiles are padded to 4), *groups
@@ -675,7 +684,7 @@ extern "C" int step_dft_fwd_seg(const float* in, const float* in_scale, const fl
                                 int frame0, void* stream) {
     STEP_REQUIRE(in && matt && spec, "step_dft_fwd: null pointer");
     STEP_REQUIRE(N >= 1 && S >= 1 && (long long)N * S <= 65535 && C >= 8 && C % 8 == 0 && C / 8 <= 65535 && K >= 1 && T >= 1 &&
-                 rows >= 32 && rows % 32 == 0 && seg_step >= 0,
+                 rows >= 4 && rows % 4 == 0 && seg_step >= 0,
                  "step_dft_fwd: bad shape N=%d C=%d T=%d K=%d rows=%d S=%d", N, C, T, K, rows, S);
     STEP_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "step_dft_fwd: scale/shift pair");
     STEP_REQUIRE(((size_t)C * T + K + (size_t)S * seg_step + 64) * 64 < (1ull << 31) && (size_t)rows * C * 64 < (1ull << 31),
@@ -693,7 +702,7 @@ extern "C" int step_dft_fwd_ph(const float* in, const float* in_scale, const flo
                                const float* matt, float* spec, int N, int C, int Tp, int rows, int phases, void* stream) {
     STEP_REQUIRE(in && matt && spec, "step_dft_fwd_ph: null pointer");
     STEP_REQUIRE(N >= 1 && N <= 65535 && C >= 8 && C % 8 == 0 && (phases == 1 || phases == 2) && C * phases / 8 <= 65535 &&
-                 Tp >= 1 && rows >= 32 && rows % 32 == 0,
+                 Tp >= 1 && rows >= 4 && rows % 4 == 0,
                  "step_dft_fwd_ph: bad shape N=%d C=%d Tp=%d rows=%d phases=%d", N, C, Tp, rows, phases);
     STEP_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "step_dft_fwd_ph: scale/shift pair");
     STEP_REQUIRE(((size_t)C * Tp + Tp + 64) * phases * 64 < (1ull << 31) && (size_t)rows * C * phases * 64 < (1ull << 31),
@@ -711,13 +720,13 @@ extern "C" int step_dft_inv_ph(const float* spec, const float* matt, float* out,
                                int phases, void* stream) {
     STEP_REQUIRE(spec && matt && out, "step_dft_inv_ph: null pointer");
     STEP_REQUIRE(N >= 1 && N <= 65535 && C >= 8 && C % 8 == 0 && (phases == 1 || phases == 2) && C * phases / 8 <= 65535 &&
-                 Tp >= 1 && rows_in >= 32 && rows_in % 32 == 0,
+                 Tp >= 1 && rows_in >= 4 && rows_in % 4 == 0,
                  "step_dft_inv_ph: bad shape N=%d C=%d rows=%d Tp=%d phases=%d", N, C, rows_in, Tp, phases);
     STEP_REQUIRE(((size_t)C * Tp + Tp + 64) * phases * 64 < (1ull << 31) && (size_t)rows_in * C * phases * 64 < (1ull << 31),
                  "step_dft_inv_ph: sample too large");
     DgParams p{};
     p.in = spec; p.matt = matt; p.out = out;
-    p.N = N; p.C = C; p.K = rows_in; p.Kpad = rows_in; p.Mpad = step::round_up((Tp + 1) / 2, 32); p.Mrows = Tp;
+    p.N = N; p.C = C; p.K = rows_in; p.Kpad = 2 * step::round_up(rows_in / 2, KC); p.Mpad = step::round_up((Tp + 1) / 2, 32); p.Mrows = Tp;
     p.S = 1; p.seg_step = 0; p.frame0 = 0; p.Tfull = Tp; p.fs = phases;
     return launch_gemm<true>(p, (hipStream_t)stream, "step_dft_inv_ph");
 }
@@ -733,7 +742,7 @@ extern "C" int step_dft_inv_seg(const float* spec, const float* matt, const floa
                                 int seg_step, double* sums, void* ws, size_t ws_bytes, void* stream) {
     STEP_REQUIRE(spec && matt && out, "step_dft_inv: null pointer");
     STEP_REQUIRE(N >= 1 && S >= 1 && (long long)N * S <= 65535 && C >= 8 && C % 8 == 0 && C / 8 <= 65535 && T_out >= 1 &&
-                 T_seg >= 1 && rows_in >= 32 && rows_in % 32 == 0 && seg_step >= 0,
+                 T_seg >= 1 && rows_in >= 4 && rows_in % 4 == 0 && seg_step >= 0,
                  "step_dft_inv: bad shape N=%d C=%d rows=%d T=%d (%d x %d)", N, C, rows_in, T_out, S, T_seg);
     STEP_REQUIRE(((size_t)C * T_out + T_seg + (size_t)S * seg_step + 64) * 64 < (1ull << 31) && (size_t)rows_in * C * 64 < (1ull << 31),
                  "step_dft_inv: sample too large");
@@ -744,7 +753,7 @@ extern "C" int step_dft_inv_seg(const float* spec, const float* matt, const floa
     p.in = spec; p.matt = matt; p.bias = bias; p.out = out;
     p.out_scale = out_scale; p.out_shift = out_shift; p.res = res; p.res_scale = res_scale; p.res_shift = res_shift;
     p.out_relu = out_relu;
-    p.N = N; p.C = C; p.K = rows_in; p.Kpad = rows_in; p.Mpad = step::round_up((T_seg + 1) / 2, 32); p.Mrows = T_seg;
+    p.N = N; p.C = C; p.K = rows_in; p.Kpad = 2 * step::round_up(rows_in / 2, KC); p.Mpad = step::round_up((T_seg + 1) / 2, 32); p.Mrows = T_seg;
     p.S = S; p.seg_step = seg_step; p.frame0 = 0; p.Tfull = T_out; p.fs = 1;
     const int groups = step_dft_groups(T_seg);
     if (sums) {

@@ -33,7 +33,7 @@ def preferred(C, Kt, T, T_out):
     rows = _lib.query("step_dft_rows", T, Kt)
     cost_dft = 1.0 * rows * (T + T_out) * C * 16 + 8.0 * C * C * 16 * (rows // 2)
     cost_direct = 2.0 * C * C * Kt * T_out * 16
-    return cost_dft < (0.6 if Kt >= 25 else 0.4) * cost_direct       # (short kernels: only with a wide margin)
+    return cost_dft < (0.6 if Kt >= 25 else 0.3) * cost_direct       # (short kernels: only with a wide margin)
 
 
 def geometry(T, Kt):
@@ -91,8 +91,9 @@ def fwd_matrix(K, step, T, Kt, device):
 
 def inv_matrix(T_out, step, T, Kt, device):
     """inverse matrix onto the pairs j < ceil(T_out/2) of frames step * t about their centre: k < NF (real rows of the
-    spectrum): kap_f / L cos(2 pi f step (j + 1/2) / L) -> E[j]; k >= NF: -kap_f / L sin(...) -> O[j]; the frames are
-    E + O and E - O.  kap_0 = 1, else 2 (L is odd: no Nyquist bin)"""
+    spectrum): kap_f / L cos(2 pi f step (j + 1/2) / L) -> E[j]; the imaginary rows: -kap_f / L sin(...) -> O[j]; the
+    frames are E + O and E - O.  kap_0 = 1, else 2 (L is odd: no Nyquist bin).  Each half is padded with zero rows to
+    NFp = round_up(NF, 16): the kernel walks the table in chunks of 16 k (csrc/tcn_dft.hip)"""
     key = ("inv", T_out, step, T, Kt, str(device))
     if key not in _TABLES:
         rows, NF, L = geometry(T, Kt)
@@ -100,7 +101,8 @@ def inv_matrix(T_out, step, T, Kt, device):
         ang = _angles2(torch.arange(NF), step * (2 * torch.arange(Th) + 1), L)          # [NF][Th]
         kap = torch.full((NF, 1), 2.0 / L, dtype=torch.float64)
         kap[0, 0] = 1.0 / L
-        m = torch.cat((kap * torch.cos(ang), -kap * torch.sin(ang)), dim=0)
+        zpad = torch.zeros(((NF + 15) // 16 * 16 - NF, Th), dtype=torch.float64)      # each half in whole chunks of 16 k
+        m = torch.cat((kap * torch.cos(ang), zpad, -kap * torch.sin(ang), zpad), dim=0)
         _TABLES[key] = _tile((m,), Th, True).to(torch.float32).to(device).contiguous()
     return _TABLES[key]
 

@@ -52,8 +52,9 @@ def inverse(re, im, T_out, step, T, Kt):
     rows, NF, L = dft.geometry(T, Kt)
     Th = (T_out + 1) // 2
     (m,) = untile(dft.inv_matrix(T_out, step, T, Kt, "cpu"), Th, True, 1)
-    assert m.shape[0] == 2 * NF
-    E, O = re @ m[:NF], im @ m[NF:]
+    NFp = (NF + 15) // 16 * 16                                # each half padded with zero rows to whole chunks of 16 k
+    assert m.shape[0] == 2 * NFp and not m[NF:NFp].any() and not m[NFp + NF:].any()
+    E, O = re @ m[:NF], im @ m[NFp:NFp + NF]
     out = np.zeros(2 * Th)
     j = np.arange(Th)
     out[Th + j], out[Th - 1 - j] = E + O, E - O
@@ -144,6 +145,6 @@ def test_cost_model_and_geometry():
             assert not dft.preferred(C, 9, T, To)
     assert not dft.preferred(3, 75, 240, 240) and not dft.supported(3, 75) and not dft.supported(64, 8)
     l = _lib.load()
-    assert l.step_dft_rows(240, 75) == 288 and l.step_dft_rows(120, 75) == 160 and l.step_dft_rows(240, 8) == 0
+    assert l.step_dft_rows(240, 75) == 280 and l.step_dft_rows(120, 75) == 160 and l.step_dft_rows(120, 39) == 140 and l.step_dft_rows(240, 8) == 0
     assert l.step_dft_groups(240) == 1 and l.step_dft_groups(1024) == 4
     assert dft.centre2(240, 1) == 239 and dft.centre2(120, 2) == 238 and dft.centre2(15, 1) == 15
