@@ -79,10 +79,16 @@ def main(src="gpurun_out"):
     # NOTE the helper launches of a run (transform of a / dout that feed the stage) share the kernel template; the
     # stage itself is the LAST launch and the only one repeated, the means below are over all launches of that name in
     # the run and are therefore used only for the stage whose launches all have one shape.
-    rows = (T + 38 + 31) // 32 * 32
-    spec = 4 * N * rows * C * 16
-    for key, st, templ, alg_d in (("dft_transform_b1", "tr", "dft_gemm_kernel<5, false>", 4 * N * C * T * 16 + spec),
-                                  ("dft_inverse_bwd_b1", "ib", "dft_gemm_kernel<4, true>", spec + 4 * N * C * T * 16)):
+    # block 1 runs as two stride-1 convs on the even / odd frames (dft.phases): T / 2 frames per phase on a grid of
+    # rows = round_up(T / 2 + 19 + 1, 4); the input's spectrum holds both phases (2 C channels), dout's C
+    rows = (T // 2 + 19 + 1 + 3) // 4 * 4
+    spec_a, spec_d = 4 * N * rows * 2 * C * 16, 4 * N * rows * C * 16
+    tens, tens_o = 4 * N * C * T * 16, 4 * N * C * (T // 2) * 16
+    for key, st, templ, alg_d in (("dft_transform_b1", "tr", "dft_gemm_kernel<3, false>", tens + spec_a),
+                                  ("dft_inverse_bwd_b1", "ib", "dft_gemm_kernel<2, true>", spec_a + tens),
+                                  ("dft_mix_b1", "mf", "dft_mix_kernel<2, 128>", spec_a + spec_d),
+                                  ("dft_mix_bwd_b1", "mb", "dft_mix_kernel<4, 64>", spec_d + spec_a),
+                                  ("dft_wgrad_b1", "wg", "dft_wgrad_kernel<2, 4>", spec_d + spec_a)):
         try:
             mfd, fed, wrd = (read(os.path.join(ROOT, src, "pmc_dft_%s_%s.txt" % (st, k))) for k in ("mfma", "fetch", "write"))
         except OSError:
@@ -99,7 +105,7 @@ def main(src="gpurun_out"):
                     "hbm_bytes": float("%.4g" % ((2 * f + w) * 1024)),
                     "command": "python3 tools/dft_bench.py --reps 1 --no-direct --only ... (tools/gpu_pmc_dft.sh)"}
     json.dump(res, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
-    for k in ("dft_transform_b1", "dft_inverse_bwd_b1"):
+    for k in ("dft_transform_b1", "dft_inverse_bwd_b1", "dft_mix_b1", "dft_mix_bwd_b1", "dft_wgrad_b1"):
         if k in res:
             e = res[k]
             print("%-18s %-30s %7.3f ms  hbm %.3g B (algorithmic %.3g)  mfma busy %.3f @ %.2f GHz" %
