@@ -89,7 +89,7 @@ struct DgParams {
 // slots per k in the table for W row tiles: fours, then a pair (3 -> 4)
 constexpr int table_slots(int W) { return (W % 4 == 0) ? W : (W % 4 == 2 ? W : W + 1); }
 
-template <int MG, bool INV>
+template <int MG, bool INV, int FS>      // FS = frames of the tensor per frame of a sequence: 1, or 2 (two interleaved phases per channel row)
 __global__ __launch_bounds__(256, 2) void dft_gemm_kernel(DgParams p) {
     constexpr int MGR = MG * 32;
     constexpr int NACC = 2 * MG;                       // INV: E tiles, then O tiles; else cos tiles, then sin tiles
@@ -111,9 +111,9 @@ __global__ __launch_bounds__(256, 2) void dft_gemm_kernel(DgParams p) {
     const int nz = blockIdx.z;                          // sample * S + segment: the spectrum's "sample"
     const int n = nz / p.S, seg = nz - n * p.S;
     const int cp = blockIdx.y * 8 + wave * 2 + cpar;    // channel of the spectrum = fs * channel of the tensor + phase
-    const int c = cp >> (p.fs - 1), ph = cp & (p.fs - 1);                   // fs is 1 or 2
-    const int CP = p.C * p.fs;
-    const unsigned fb = 64u * (unsigned)p.fs;           // bytes from a frame of a phase to its next
+    const int c = cp >> (FS - 1), ph = cp & (FS - 1);                       // FS is 1 or 2
+    const int CP = p.C * FS;
+    constexpr unsigned fb = 64u * FS;                   // bytes from a frame of a phase to its next (compile-time: the k offsets stay immediates)
 
     // B operand addressing: descriptor on the sample, lane offsets, uniform k offsets
     const size_t sample = INV ? (size_t)CP * p.K * 16 : (size_t)CP * p.Tfull * 16;
@@ -122,8 +122,8 @@ __global__ __launch_bounds__(256, 2) void dft_gemm_kernel(DgParams p) {
     const int mf = p.frame0 + seg * p.seg_step;         // INV == 0: the window's first frame in the row (may be negative)
     const unsigned kstride = INV ? (unsigned)CP * 64u : fb;                         // bytes per k
     const unsigned voff = INV ? (unsigned)cp * 64u + half * kstride + v * 4u
-                              : (unsigned)(((c * p.Tfull + mf + Kh + half) * p.fs + ph) * 64 + v * 4);     // frame hi of pair `half`
-    const unsigned voff_lo = (unsigned)(((c * p.Tfull + mf + Kh - 1 - half) * p.fs + ph) * 64 + v * 4);     // frame lo
+                              : (unsigned)(((c * p.Tfull + mf + Kh + half) * FS + ph) * 64 + v * 4);       // frame hi of pair `half`
+    const unsigned voff_lo = (unsigned)(((c * p.Tfull + mf + Kh - 1 - half) * FS + ph) * 64 + v * 4);       // frame lo
     float sc = 1.f, sh = 0.f;
     const bool act = !INV && p.in_scale != nullptr;
     if (act) { sc = p.in_scale[c]; sh = p.in_shift[c]; }
@@ -162,6 +162,19 @@ __global__ __launch_bounds__(256, 2) void dft_gemm_kernel(DgParams p) {
     [[maybe_unused]] const int nre = nchunk >> 1;
     [[maybe_unused]] const int kpadh = (p.Kpad - p.K) >> 1;
     auto load_b = [&](int kc, float (&b)[NB]) {
+        [[maybe_unused]] int rowbase = 0;
+        if constexpr (INV) {
+            // first row of the chunk in the spectrum; a chunk that lies inside its half needs no clamp (uniform branch):
+            // one scalar base, compile-time steps
+            const int kin = (kc >= nre ? kc - nre : kc) * KC;
+            rowbase = kc * KC - (kc >= nre ? kpadh : 0);
+            if (kin + KC <= (p.K >> 1)) {
+                const unsigned sb = (unsigned)rowbase * kstride;
+#pragma unroll
+                for (int ks = 0; ks < KC / 2; ++ks) b[ks] = bload(rs, voff, sb + (unsigned)(2 * ks) * kstride);
+                return;
+            }
+        }
         if constexpr (!INV) {
             // a chunk whose 16 pairs all have both frames (every chunk but the last, and the first of a segment at the
             // row's start) needs no masks: 64 VALU instructions fewer beside the MFMA stream (uniform branch)
@@ -184,8 +197,7 @@ __global__ __launch_bounds__(256, 2) void dft_gemm_kernel(DgParams p) {
         for (int ks = 0; ks < KC / 2; ++ks) {
             const int k = kc * KC + 2 * ks;                                  // (+ half: in the lane offsets)
             if constexpr (INV) {
-                const int row = min(k - (kc >= nre ? kpadh : 0), p.K - 2);
-                b[ks] = bload(rs, voff, (unsigned)row * kstride);
+                b[ks] = bload(rs, voff, (unsigned)min(rowbase + 2 * ks, p.K - 2) * kstride);       // (a chunk with padding rows)
             } else {
                 float xh = bload(rs, voff + (unsigned)k * fb, 0u);      // (offsets in the VGPR: the range check sees all of them)
                 float xl = bload(rs, voff_lo - (unsigned)k * fb, 0u);
@@ -275,8 +287,8 @@ __global__ __launch_bounds__(256, 2) void dft_gemm_kernel(DgParams p) {
         const __amdgpu_buffer_rsrc_t ro = rsrc_n(p.out + (size_t)n * osample, (unsigned)(osample * 4));
         const __amdgpu_buffer_rsrc_t rr = rsrc_n(p.res ? p.res + (size_t)n * osample : p.out, p.res ? (unsigned)(osample * 4) : 0u);
         const int j0 = m0 + 4 * half;
-        const unsigned ol_hi = (unsigned)((((c * p.Tfull + fo + Th + j0) * p.fs + ph) * 16 + v) * 4);
-        const unsigned ol_lo = (unsigned)((((c * p.Tfull + fo + Th - 1 - j0) * p.fs + ph) * 16 + v) * 4);
+        const unsigned ol_hi = (unsigned)((((c * p.Tfull + fo + Th + j0) * FS + ph) * 16 + v) * 4);
+        const unsigned ol_lo = (unsigned)((((c * p.Tfull + fo + Th - 1 - j0) * FS + ph) * 16 + v) * 4);
         // pairs (relative to the lane's first) whose lo / hi frame exists - in the segment and in the row
         const int nlo = Th - j0, nhi_o = min(p.Mrows, p.Tfull - fo) - Th - j0, nlo_min = fo + Th - j0 - p.Tfull;
         float s1 = 0.f, s2 = 0.f;
@@ -392,47 +404,68 @@ __global__ __launch_bounds__(64 * mix_waves(CT, CI), 8 / mix_waves(CT, CI)) void
             for (int ks = 0; ks < CIH / 2; ++ks)
                 b[part * (CIH / 2) + ks] = bload(rs, in_lane + part * part_jump + (unsigned)(h * CIH * 64), (unsigned)(ks * 128));
     };
-    f32x16 k1, k2, k3;
-    auto mac = [&](const float (&b)[CIH], int h) {
-#pragma unroll
-        for (int kk = 0; kk < CIH / 2; ++kk) {
-            const f32x4 w = *reinterpret_cast<const f32x4*>(wlane + (h * (CIH / 2) + kk) * 256);
-            const float xr = b[kk], xi = b[CIH / 2 + kk];
-            k1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[0], xr, k1, 0, 0, 0);
-            k2 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[1], xi - xr, k2, 0, 0, 0);
-            k3 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[2], xr + xi, k3, 0, 0, 0);
-            if ((kk & 3) == 3) __builtin_amdgcn_sched_barrier(0);           // keep the LDS reads 4 k-steps ahead at most (registers)
-        }
-    };
     int pr = p0 + stream;
     if (pr < p1) load_pair(pr, 0, bc);
-    for (; pr < p1; pr += STREAMS) {
-        if constexpr (KH == 1) {
+    if constexpr (KH == 1) {
+        // (the loop bodies are written out, not shared through lambdas: the compiler then packs the operand sums /
+        // differences and the epilogue's adds in pairs - 8 VALU instructions fewer per pair)
+        for (; pr < p1; pr += STREAMS) {
             if (pr + STREAMS < p1) load_pair(pr + STREAMS, 0, bn);
-        } else {
-            load_pair(pr, 1, bn);
-        }
+            f32x16 q1, q2, q3;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { k1[r] = 0.f; k2[r] = 0.f; k3[r] = 0.f; }
-        mac(bc, 0);
-        if constexpr (KH == 2) {
-            if (pr + STREAMS < p1) load_pair(pr + STREAMS, 0, bc);
-            mac(bn, 1);
-        }
-        const int have = min(2, p.N - 2 * pr);
-        const __amdgpu_buffer_rsrc_t ro = rsrc_n(p.out + (size_t)(2 * pr) * out_sample, (unsigned)(have * out_sample * 4));
-        const f32x16 re = k1 - k3, im = k1 + k2;
+            for (int r = 0; r < 16; ++r) { q1[r] = 0.f; q2[r] = 0.f; q3[r] = 0.f; }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            bstore(ro, out_lane[r], 0u, re[r]);
-            bstore(ro, out_lane[r], im_jump, im[r]);          // (the uniform jump in the SGPR offset: the pair's descriptor covers it)
-        }
-        if constexpr (KH == 1) {
+            for (int kk = 0; kk < CI / 2; ++kk) {
+                const f32x4 w = *reinterpret_cast<const f32x4*>(wlane + kk * 256);
+                const float xr = bc[kk], xi = bc[CI / 2 + kk];
+                q1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[0], xr, q1, 0, 0, 0);
+                q2 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[1], xi - xr, q2, 0, 0, 0);
+                q3 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[2], xr + xi, q3, 0, 0, 0);
+                if ((kk & 3) == 3) __builtin_amdgcn_sched_barrier(0);           // keep the LDS reads 4 k-steps ahead at most (registers)
+            }
+            const int have = min(2, p.N - 2 * pr);
+            const __amdgpu_buffer_rsrc_t ro = rsrc_n(p.out + (size_t)(2 * pr) * out_sample, (unsigned)(have * out_sample * 4));
+            const f32x16 re = q1 - q3, im = q1 + q2;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                bstore(ro, out_lane[r], 0u, re[r]);
+                bstore(ro, out_lane[r], im_jump, im[r]);          // (the uniform jump in the SGPR offset: the pair's descriptor covers it)
+            }
             if (pr + STREAMS < p1) {
 #pragma unroll
                 for (int kk = 0; kk < CI; ++kk) bc[kk] = bn[kk];
             }
         }
+    } else {
+        // K = 128: the second half of a pair is requested while its first half multiplies, the next pair's first half
+        // while the second does - the two register sets swap roles, no copies
+#define MIX_MAC(B, H)                                                                                                  \
+        _Pragma("unroll") for (int kk = 0; kk < CIH / 2; ++kk) {                                                       \
+            const f32x4 w = *reinterpret_cast<const f32x4*>(wlane + ((H) * (CIH / 2) + kk) * 256);                     \
+            const float xr = B[kk], xi = B[CIH / 2 + kk];                                                              \
+            q1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[0], xr, q1, 0, 0, 0);                                          \
+            q2 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[1], xi - xr, q2, 0, 0, 0);                                     \
+            q3 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[2], xr + xi, q3, 0, 0, 0);                                     \
+            if ((kk & 3) == 3) __builtin_amdgcn_sched_barrier(0);                                                      \
+        }
+        for (; pr < p1; pr += STREAMS) {
+            load_pair(pr, 1, bn);
+            f32x16 q1, q2, q3;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { q1[r] = 0.f; q2[r] = 0.f; q3[r] = 0.f; }
+            MIX_MAC(bc, 0)
+            if (pr + STREAMS < p1) load_pair(pr + STREAMS, 0, bc);
+            MIX_MAC(bn, 1)
+            const int have = min(2, p.N - 2 * pr);
+            const __amdgpu_buffer_rsrc_t ro = rsrc_n(p.out + (size_t)(2 * pr) * out_sample, (unsigned)(have * out_sample * 4));
+            const f32x16 re = q1 - q3, im = q1 + q2;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                bstore(ro, out_lane[r], 0u, re[r]);
+                bstore(ro, out_lane[r], im_jump, im[r]);
+            }
+        }
+#undef MIX_MAC
     }
 }
 
@@ -630,7 +663,10 @@ int launch_gemm(DgParams p, hipStream_t st, const char* what) {
     const int mg = pick_mg(mtiles, INV);
     const int groups = step::ceil_div(mtiles, mg);
     const dim3 grid((unsigned)groups, (unsigned)(p.C * p.fs / 8), (unsigned)(p.N * p.S));
-#define DG_CASE(MGV) case MGV: hipLaunchKernelGGL((dft_gemm_kernel<MGV, INV>), grid, dim3(256), 0, st, p); return step::check_launch(what)
+#define DG_CASE(MGV) case MGV:                                                                                              \
+        if (p.fs == 2) hipLaunchKernelGGL((dft_gemm_kernel<MGV, INV, 2>), grid, dim3(256), 0, st, p);                       \
+        else hipLaunchKernelGGL((dft_gemm_kernel<MGV, INV, 1>), grid, dim3(256), 0, st, p);                                 \
+        return step::check_launch(what)
     if constexpr (INV) {
         switch (mg) { DG_CASE(2); DG_CASE(3); DG_CASE(4); default: break; }
     } else {
