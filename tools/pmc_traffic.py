@@ -84,8 +84,8 @@ def main(src="gpurun_out"):
     rows = (T // 2 + 19 + 1 + 3) // 4 * 4
     spec_a, spec_d = 4 * N * rows * 2 * C * 16, 4 * N * rows * C * 16
     tens, tens_o = 4 * N * C * T * 16, 4 * N * C * (T // 2) * 16
-    for key, st, templ, alg_d in (("dft_transform_b1", "tr", "dft_gemm_kernel<3, false>", tens + spec_a),
-                                  ("dft_inverse_bwd_b1", "ib", "dft_gemm_kernel<2, true>", spec_a + tens),
+    for key, st, templ, alg_d in (("dft_transform_b1", "tr", "dft_gemm_kernel<3, false, 2>", tens + spec_a),
+                                  ("dft_inverse_bwd_b1", "ib", "dft_gemm_kernel<2, true, 2>", spec_a + tens),
                                   ("dft_mix_b1", "mf", "dft_mix_kernel<2, 128>", spec_a + spec_d),
                                   ("dft_mix_bwd_b1", "mb", "dft_mix_kernel<4, 64>", spec_d + spec_a),
                                   ("dft_wgrad_b1", "wg", "dft_wgrad_kernel<2, 4>", spec_d + spec_a)):
