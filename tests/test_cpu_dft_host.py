@@ -148,3 +148,24 @@ def test_cost_model_and_geometry():
     assert l.step_dft_rows(240, 75) == 280 and l.step_dft_rows(120, 75) == 160 and l.step_dft_rows(120, 39) == 140 and l.step_dft_rows(240, 8) == 0
     assert l.step_dft_groups(240) == 1 and l.step_dft_groups(1024) == 4
     assert dft.centre2(240, 1) == 239 and dft.centre2(120, 2) == 238 and dft.centre2(15, 1) == 15
+
+
+def test_host_side_shape_guards_refuse_mismatched_spectra():
+    """the kernels trust their arguments, so step_amd/dft.py checks shapes before it calls them: weights of the other
+    mixing form, a spectrum on the wrong grid and a one-phase spectrum handed to the two-phase weight gradient raise
+    (no GPU needed: the guards fire before any launch)"""
+    C, T, Kt = 64, 240, 75
+    rows_full = dft.geometry(T, Kt)[0]
+    rows_ph = dft.geometry(*dft.phase_geometry(T, Kt))[0]
+    assert (rows_full, rows_ph) == (280, 140)
+    spec = torch.zeros(1, rows_full, C, 16)
+    with pytest.raises(_lib.StepHipError, match="mix"):
+        dft.mix(spec, torch.zeros((rows_full // 2) * 4 * C * 2 * C), C)        # 2C -> C weights, C -> C call
+    with pytest.raises(_lib.StepHipError, match="mix"):
+        dft.mix(torch.zeros(1, rows_ph, C, 16), torch.zeros(7), 2 * C, C)      # channel count / weight size mismatch
+    with pytest.raises(_lib.StepHipError, match="conv_wgrad"):
+        dft.conv_wgrad(torch.zeros(1, rows_ph, C, 16), torch.zeros(1, rows_ph, C, 16), T, Kt, False, (C, C, Kt, 1), T // 2, 2)
+    with pytest.raises(_lib.StepHipError, match="conv_dgrad"):
+        dft.conv_dgrad(spec, torch.zeros(1), T, Kt, 2, False)                  # dout's spectrum must be on the phase grid
+    with pytest.raises(_lib.StepHipError, match="inverse"):
+        dft.inverse(torch.zeros(1, rows_ph, C, 16), None, T, 1, T, Kt)
