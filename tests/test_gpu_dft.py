@@ -14,7 +14,10 @@ CASES = [(64, 1, 33, 2, False, 75), (32, 1, 50, 3, False, 75), (64, 2, 41, 2, Fa
          (64, 1, 120, 5, False, 75), (32, 1, 24, 2, True, 75), (64, 1, 75, 4, True, 75), (64, 1, 18, 3, False, 75),
          (64, 2, 120, 3, False, 9), (32, 1, 240, 2, False, 9), (64, 1, 300, 2, False, 75),
          # stride 2 with an even T runs as two stride-1 convs on the even / odd frames (dft.phases): 2 C -> C mixing
-         (32, 2, 60, 3, False, 75), (64, 2, 18, 5, False, 75), (32, 2, 240, 2, False, 9), (64, 2, 150, 1, False, 75)]
+         (32, 2, 60, 3, False, 75), (64, 2, 18, 5, False, 75), (32, 2, 240, 2, False, 9), (64, 2, 150, 1, False, 75),
+         # ... with several row-tile groups per phase (T = 1024: 9 tiles in 3 groups), one 5-tile group (T = 600), and the
+         # smallest grids (one frame per phase; 4 spectrum rows)
+         (32, 2, 1024, 1, False, 75), (64, 2, 600, 1, False, 75), (64, 2, 2, 3, False, 3), (32, 2, 4, 2, False, 9)]
 
 
 @pytest.mark.parametrize("C,stride,T,N,tr,Kt", CASES)
