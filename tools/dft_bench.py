@@ -64,15 +64,14 @@ def main():
     inv_b = (lambda: dft._lib.call("step_dft_inv_ph", smb, dft.inv_matrix(tp, 1, tp, ktp, d), torch.empty_like(y), n, c, rows, tp, 2)) \
         if ph == 2 else (lambda: dft.inverse(smb, None, t, 1, t, kt))
     fl = 2.0 * c * c * kt * to * 16 * n
-    fin = t if ph == 1 else t          # frames a full-rate transform handles (both phases together)
     stages = [
         ("wspec", lambda: dft.weight_spectrum(w, c, t, kt, False, to, s), 0),
-        ("fwd: transform(a)", tr_a, 1.0 * rows * fin * c * 16 * n),
+        ("fwd: transform(a)", tr_a, 1.0 * rows * t * c * 16 * n),
         ("fwd: mix", mix_f, 2.0 * 3 * c * c * ph * 16 * NF * n),
         ("fwd: inverse(+stats)", inv_f, 1.0 * rows * to * c * 16 * n),
         ("bwd: transform(du)", lambda: dft.transform_dout(du, s, t, kt), 1.0 * rows * to * c * 16 * n),
         ("bwd: mix", mix_b, 2.0 * 3 * c * c * ph * 16 * NF * n),
-        ("bwd: inverse", inv_b, 1.0 * rows * fin * c * 16 * n),
+        ("bwd: inverse", inv_b, 1.0 * rows * t * c * 16 * n),
         ("bwd: wgrad", lambda: dft.conv_wgrad(sdu, sa, t, kt, False, tuple(w.shape), to, s), 2.0 * 3 * c * c * ph * 16 * NF * n),
     ]
     tot = {"fwd": 0.0, "bwd": 0.0}
