@@ -544,6 +544,110 @@ __global__ __launch_bounds__(64 * CT * CTN) __attribute__((amdgpu_num_vgpr(128))
         }
 }
 
+// The same products with the operands shared through LDS (blocks of more than one wave).  In the form above every wave
+// requests its own (co tile, ci tile) rows from memory: a du^ tile is requested by CTN waves, an a^ tile by CT, and most
+// of those requests miss in L2 while the first is in flight - PMC at 64 x 128: 13.3 GB moved for 7.05 GB, 132 M TCC
+// requests / 104 M misses for 55 M distinct lines.  Here the block copies the bin's rows of one sample - du^ re | im
+// (2 Co rows), a^ re | im (2 Ci rows), 64 bytes each, every group contiguous in HBM - into LDS once (coalesced 16-byte
+// loads, two samples ahead in registers), rows at a pitch of 80 bytes: a wave's 16-byte fragment reads (lane = row, the two
+// halves 32 bytes apart) then touch every bank once per 16 lanes.  Double-buffered, one barrier per sample.
+template <int CT, int CTN>
+__global__ __launch_bounds__(64 * CT * CTN) __attribute__((amdgpu_num_vgpr(128))) void dft_wgrad_lds_kernel(WgParams p) {
+    constexpr int NT = 64 * CT * CTN;
+    constexpr int CO = 32 * CT, CI = 32 * CTN;
+    constexpr int ROWS = 2 * (CO + CI);                 // du^ re, du^ im, a^ re, a^ im
+    constexpr int PITCH = 20;                           // floats per row in LDS (16 + 4 of padding)
+    constexpr int NL = (ROWS * 4 + NT - 1) / NT;        // 16-byte pieces per thread and sample
+    static_assert((ROWS * 4) % NT == 0, "the copy divides evenly");
+    __shared__ __attribute__((aligned(16))) float lbuf[2 * ROWS * PITCH];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int f = blockIdx.x, split = blockIdx.y;
+    const int wm = wave / CTN, wn = wave % CTN;
+    const int n0 = (int)((long long)p.N * split / p.nsplit), n1 = (int)((long long)p.N * (split + 1) / p.nsplit);
+    const size_t ds_sample = (size_t)2 * p.NF * CO * 16, s_sample = (size_t)2 * p.NF * CI * 16;
+
+    // copy: piece q = tid + j * NT -> row q / 4, quarter q % 4; the source group of a row is uniform per (j, wave) except
+    // at group boundaries, so the offsets are computed per thread once
+    size_t goff[NL];                                    // float offset within the sample of ds (rows < 2 CO) or s
+    int loff[NL];
+    bool from_s[NL];
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+        const int q = tid + j * NT, row = q >> 2, quarter = q & 3;
+        loff[j] = row * PITCH + quarter * 4;
+        from_s[j] = row >= 2 * CO;
+        if (!from_s[j]) {
+            const int im = row >= CO, r = row - im * CO;
+            goff[j] = ((size_t)(im * p.NF + f) * CO + r) * 16 + quarter * 4;
+        } else {
+            const int r2 = row - 2 * CO, im = r2 >= CI, r = r2 - im * CI;
+            goff[j] = ((size_t)(im * p.NF + f) * CI + r) * 16 + quarter * 4;
+        }
+    }
+    f32x4 sta[NL], stb[NL];                             // two samples in flight: the copy runs two samples ahead of the MFMAs
+    auto gload = [&](int n, f32x4 (&st)[NL]) {
+#pragma unroll
+        for (int j = 0; j < NL; ++j)
+            st[j] = *reinterpret_cast<const f32x4*>((from_s[j] ? p.s + (size_t)n * s_sample : p.ds + (size_t)n * ds_sample) + goff[j]);
+    };
+    auto lstore = [&](int b, const f32x4 (&st)[NL]) {
+#pragma unroll
+        for (int j = 0; j < NL; ++j) *reinterpret_cast<f32x4*>(&lbuf[b * ROWS * PITCH + loff[j]]) = st[j];
+    };
+    // fragments: row = tile * 32 + l31, joints 8 half .. 8 half + 7 as two float4
+    const int fa = (wm * 32 + l31) * PITCH + 8 * half;                 // du^ re; im: + CO rows
+    const int fb = (2 * CO + wn * 32 + l31) * PITCH + 8 * half;        // a^ re; im: + CI rows
+
+    f32x16 acc[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    // sample n: multiply from LDS buffer b while sample n + 2 is requested into `nxt2`; then `nxt1` (sample n + 1, requested
+    // an iteration ago) goes to the other buffer; the two register sets swap roles from sample to sample
+    auto do_sample = [&](int n, int b, const f32x4 (&nxt1)[NL], f32x4 (&nxt2)[NL]) {
+        if (n + 2 < n1) gload(n + 2, nxt2);
+        const float* L = lbuf + b * ROWS * PITCH;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const f32x4 dr = *reinterpret_cast<const f32x4*>(L + fa + 4 * h);
+            const f32x4 di = *reinterpret_cast<const f32x4*>(L + fa + CO * PITCH + 4 * h);
+            const f32x4 ar = *reinterpret_cast<const f32x4*>(L + fb + 4 * h);
+            const f32x4 ai = *reinterpret_cast<const f32x4*>(L + fb + CI * PITCH + 4 * h);
+            const f32x4 dm = dr - di, bd = ai - ar, bs = ar + ai;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(dm[e], ar[e], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(dr[e], bd[e], acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(di[e], bs[e], acc[2], 0, 0, 0);
+            }
+        }
+        if (n + 1 < n1) lstore(b ^ 1, nxt1);
+        __syncthreads();
+    };
+    if (n0 < n1) {
+        gload(n0, sta);
+        if (n0 + 1 < n1) gload(n0 + 1, stb);
+        lstore(0, sta);
+    }
+    __syncthreads();
+    for (int n = n0; n < n1; n += 2) {
+        do_sample(n, 0, stb, sta);                      // stb holds n + 1; sta takes n + 2
+        if (n + 1 < n1) do_sample(n + 1, 1, sta, stb);
+    }
+    float* dst = p.part + ((size_t)f * p.nsplit + split) * 3 * CO * CI;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = wm * 32 + rowmap(r, half), ci = wn * 32 + l31;
+            dst[((size_t)i * CO + co) * CI + ci] = acc[i][r];
+        }
+}
+
 // C^[f][co][ci] = kap_f / L * ordered sum over the batch slices of (P1 + P3, P1 + P2); then
 // dw[co][ci][j] = SUM_f (C^r[f] tc[f][j] - C^i[f] ts[f][j]);  db[co] = SUM_(n,v) du^[n][0][co][v] in a fixed order.
 // tc / ts: [NF][Kt] cos / sin of 2 pi f (j - P) / L.
@@ -886,10 +990,19 @@ extern "C" int step_dft_wgrad(const float* dspec, const float* spec, const float
     hipStream_t st = (hipStream_t)stream;
     WgParams p{dspec, spec, (float*)ws, N, Ci, Co, NF, wgrad_nsplit(N, NF, Co, Ci)};
     const dim3 grid((unsigned)NF, (unsigned)p.nsplit);
-    if (Co == 64 && Ci == 128) hipLaunchKernelGGL((dft_wgrad_kernel<2, 4>), grid, dim3(512), 0, st, p);
-    else if (Co == 64) hipLaunchKernelGGL((dft_wgrad_kernel<2, 2>), grid, dim3(256), 0, st, p);
-    else if (Ci == 64) hipLaunchKernelGGL((dft_wgrad_kernel<1, 2>), grid, dim3(128), 0, st, p);
-    else hipLaunchKernelGGL((dft_wgrad_kernel<1, 1>), grid, dim3(64), 0, st, p);
+    static const bool direct = getenv("STEP_DFT_WGRAD_DIRECT") != nullptr;      // (same-box A/B: every wave loads its own operands)
+    if (Co == 64 && Ci == 128) {
+        if (direct) hipLaunchKernelGGL((dft_wgrad_kernel<2, 4>), grid, dim3(512), 0, st, p);
+        else hipLaunchKernelGGL((dft_wgrad_lds_kernel<2, 4>), grid, dim3(512), 0, st, p);
+    } else if (Co == 64) {
+        if (direct) hipLaunchKernelGGL((dft_wgrad_kernel<2, 2>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((dft_wgrad_lds_kernel<2, 2>), grid, dim3(256), 0, st, p);
+    } else if (Ci == 64) {
+        if (direct) hipLaunchKernelGGL((dft_wgrad_kernel<1, 2>), grid, dim3(128), 0, st, p);
+        else hipLaunchKernelGGL((dft_wgrad_lds_kernel<1, 2>), grid, dim3(128), 0, st, p);
+    } else {
+        hipLaunchKernelGGL((dft_wgrad_kernel<1, 1>), grid, dim3(64), 0, st, p);
+    }
     int rc = step::check_launch("step_dft_wgrad");
     if (rc != STEP_OK) return rc;
     float* chat = (float*)ws + (size_t)NF * p.nsplit * 3 * Ci * Co;

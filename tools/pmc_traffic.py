@@ -88,7 +88,7 @@ def main(src="gpurun_out"):
                                   ("dft_inverse_bwd_b1", "ib", "dft_gemm_kernel<2, true, 2>", spec_a + tens),
                                   ("dft_mix_b1", "mf", "dft_mix_kernel<2, 128>", spec_a + spec_d),
                                   ("dft_mix_bwd_b1", "mb", "dft_mix_kernel<4, 64>", spec_d + spec_a),
-                                  ("dft_wgrad_b1", "wg", "dft_wgrad_kernel<2, 4>", spec_d + spec_a)):
+                                  ("dft_wgrad_b1", "wg", "dft_wgrad_lds_kernel<2, 4>", spec_d + spec_a)):
         try:
             mfd, fed, wrd = (read(os.path.join(ROOT, src, "pmc_dft_%s_%s.txt" % (st, k))) for k in ("mfma", "fetch", "write"))
         except OSError:
